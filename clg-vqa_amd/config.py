@@ -1,0 +1,155 @@
+"""Model / task configuration surface of the VQA fine-tuning hot path.
+
+Keeps the reference's `volta.config` surface (SURVEY.md §8b "KEEP SURFACE"):
+
+* ``BertConfig.from_json_file`` / ``from_dict`` -- reference ``volta/volta/config.py:389-401``:
+  construct with ctor defaults, then overwrite attributes with whatever the JSON holds, so keys
+  missing from the JSON keep the ctor default (UC2: ``fusion_act="relu"``, ``config.py:254``).
+* ``M3PConfig`` -- reference ``volta/volta/config.py:416-609`` (XLM-style names ``emb_dim``,
+  ``n_heads``, ``n_layers``; defaults ``layer_norm_eps=1e-12``, ``n_layers=12``).
+* ``load_task_cfg`` -- the ``config_tasks/*.yml`` surface, reference ``volta/train_task.py:169-177``.
+
+Only the keys the UC2 / M3P VQA path reads are interpreted by the engine; every other key is carried
+through untouched so a reference JSON round-trips.
+"""
+import copy
+import json
+
+_BERT_DEFAULTS = dict(
+    vocab_size=-1, hidden_size=768, num_attention_heads=12, intermediate_size=3072, pooler_size=768,
+    hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+    max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12,
+    initializer_range=0.02,
+    # vision stream
+    num_locs=5, v_coordinate_embeddings_dim=None, add_global_imgfeat=None, image_embeddings="vilbert",
+    v_feature_size=2048, v_hidden_size=768, v_num_attention_heads=12, v_intermediate_size=3072,
+    v_attention_probs_dropout_prob=0.1, v_hidden_act="gelu", v_hidden_dropout_prob=0.1,
+    v_initializer_range=0.2, v_pooler_size=1024,
+    # sub-layer topology (data driven; the engine accepts only the UC2 pattern)
+    tt_attn_sublayers=[], tv_attn_sublayers=[], vt_attn_sublayers=[], vv_attn_sublayers=[],
+    t_ff_sublayers=[], v_ff_sublayers=[], shared_sublayers=[], single_ln_sublayers=[],
+    sublayer2attn_hidden_size={}, sublayer2num_attention_heads={}, sublayer2intermediate_size={},
+    sublayer2v_attn_hidden_size={}, sublayer2v_num_attention_heads={}, sublayer2v_intermediate_size={},
+    bert_layer2attn_sublayer={}, bert_layer2ff_sublayer={}, image_head_ln=True, itm_dim=2,
+    # misc
+    visual_target_weights={"0": 1}, fixed_layers=[], model="bert", m_encoder=None, m_layer=0,
+    v_layers=[], has_mapping="linear", has_mapping_bias=False, load_x_model=False, fixed_embs=None,
+    norm_embeddings=False, fusion_method="mul", fusion_act="relu", objective=0,
+    clf_hidden_size=1536, visualization=False,
+)
+
+_M3P_DEFAULTS = dict(
+    vocab_size=-1, hidden_size=768, n_heads=12, intermediate_size=3072, pooler_size=768,
+    hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+    max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12,
+    num_locs=5, image_embeddings="vilbert", initializer_range=0.02, v_feature_size=2048,
+    v_hidden_size=768, norm_embeddings=False, fixed_layers=[], fusion_act="relu",
+    clf_hidden_size=1536, model="bert", n_langs=100, n_words=250002, eos_index=2, pad_index=1,
+    emb_dim=768, n_layers=12, dropout=0.1, attention_dropout=0.1, gelu_activation=True,
+    sinusoidal_embeddings=False, fusion_method="text",
+)
+
+
+class _ConfigBase(object):
+    _defaults = {}
+
+    def __init__(self, vocab_size_or_config_json_file=-1, **kwargs):
+        for k, v in self._defaults.items():
+            self.__dict__[k] = copy.deepcopy(v)
+        if isinstance(vocab_size_or_config_json_file, str):
+            with open(vocab_size_or_config_json_file, "r", encoding="utf-8") as reader:
+                for k, v in json.loads(reader.read()).items():
+                    self.__dict__[k] = v
+        elif isinstance(vocab_size_or_config_json_file, int):
+            self.vocab_size = vocab_size_or_config_json_file
+        else:
+            raise ValueError("First argument must be either a vocabulary size (int) "
+                             "or the path to a pretrained model config file (str)")
+        for k, v in kwargs.items():
+            self.__dict__[k] = v
+
+    @classmethod
+    def from_dict(cls, json_object):
+        config = cls(vocab_size_or_config_json_file=-1)
+        for key, value in json_object.items():
+            config.__dict__[key] = value
+        return config
+
+    @classmethod
+    def from_json_file(cls, json_file):
+        with open(json_file, "r", encoding="utf-8") as reader:
+            return cls.from_dict(json.loads(reader.read()))
+
+    def to_dict(self):
+        return copy.deepcopy(self.__dict__)
+
+    def to_json_string(self):
+        return json.dumps(self.to_dict(), indent=2, sort_keys=True) + "\n"
+
+    def __repr__(self):
+        return str(self.to_json_string())
+
+
+class BertConfig(_ConfigBase):
+    """Reference ``volta/volta/config.py:218-415``."""
+    _defaults = _BERT_DEFAULTS
+
+
+class M3PConfig(_ConfigBase):
+    """Reference ``volta/volta/config.py:416-609``."""
+    _defaults = _M3P_DEFAULTS
+
+
+class TaskCfg(dict):
+    """Attribute-style dict standing in for ``easydict.EasyDict`` (absent from the image)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _to_taskcfg(obj):
+    if isinstance(obj, dict):
+        return TaskCfg({k: _to_taskcfg(v) for k, v in obj.items()})
+    if isinstance(obj, list):
+        return [_to_taskcfg(v) for v in obj]
+    return obj
+
+
+def load_task_cfg(yaml_path):
+    """``yaml.safe_load`` -> attribute dict keyed ``TASK{id}`` (reference ``train_task.py:169-177``)."""
+    import yaml
+    with open(yaml_path, "r") as f:
+        return _to_taskcfg(yaml.safe_load(f))
+
+
+def uc2_topology_check(config):
+    """The native engine supports exactly the UC2 sub-layer pattern (SURVEY.md §5 Config row):
+    all four attention types on the even sub-layers, feed-forward on the odd ones, everything
+    shared and single-LN.  Anything else is rejected loudly instead of being silently mis-run.
+    Returns the number of transformer layers."""
+    tt, tv, vt, vv = (list(config.tt_attn_sublayers), list(config.tv_attn_sublayers),
+                      list(config.vt_attn_sublayers), list(config.vv_attn_sublayers))
+    tff, vff = list(config.t_ff_sublayers), list(config.v_ff_sublayers)
+    n_sub = len(tt) + len(tff)
+    ok = (tt == tv == vt == vv and tff == vff and n_sub % 2 == 0 and n_sub > 0
+          and tt == list(range(0, n_sub, 2)) and tff == list(range(1, n_sub, 2))
+          and sorted(config.shared_sublayers) == list(range(n_sub))
+          and sorted(config.single_ln_sublayers) == list(range(n_sub))
+          and config.hidden_size == config.v_hidden_size
+          and config.num_attention_heads == config.v_num_attention_heads
+          and config.intermediate_size == config.v_intermediate_size
+          and not config.sublayer2attn_hidden_size and not config.sublayer2intermediate_size
+          and config.image_embeddings == "uc2" and config.fusion_method == "text"
+          and config.hidden_act == "gelu" and config.v_hidden_act == "gelu")
+    if not ok:
+        raise ValueError(
+            "clg_vqa_amd: only the UC2 single-stream topology is supported by the native engine "
+            "(tt=tv=vt=vv on even sub-layers, ff on odd, all shared + single_ln, image_embeddings='uc2', "
+            "fusion_method='text', gelu); got an unsupported volta config")
+    return n_sub // 2
