@@ -1,0 +1,355 @@
+// vl_attn_fwd / vl_attn_bwd: the fused V&L attention core over the single stream X = [text ; boxes].
+//
+// Reference: volta/volta/encoders.py:255-341 (BertGatedSelfAttention.forward).  With UC2's has_tt = has_tv =
+// has_vt = has_vv and shared weights, the four gated score blocks, the two concatenated softmaxes
+// (cat(tt,tv) for text rows, cat(vt,vv) for box rows -- key order [text, boxes] for both, :288-307), the four
+// dropouts and the four P.V products are exactly ONE multi-head attention over S = T + V tokens with the
+// additive key mask [t_mask ; v_mask] (encoders.py:978-995).  Queries at padded positions are still computed.
+//
+// One workgroup (4 waves) per (batch, head).  K and V tiles (S x 64 fp32) are staged in LDS once and shared by
+// the 4 waves; scores, softmax and P.V run on the exact-fp32 matrix pipe (v_mfma_f32_16x16x4_f32), so this
+// kernel adds no rounding beyond fp32 (the QKV projection feeding it is the 3-pass bf16 GEMM).  S <= 160 means
+// the whole key range of a query tile lives in registers: a plain (not online) softmax.
+//
+// MFMA 16x16x4 f32 operand maps (cdna guide §3): A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// C/D: col = lane&15, row = 4*(lane>>4) + reg.
+#include "common.h"
+#include "../../include/vlhip.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int LDT = 66;  // padded row length (floats) of the [row][64] LDS tiles: rows land on distinct banks
+
+struct AttnArgs {
+  const float* qkv; const float* addmask; bf16_raw* ctx_hi; bf16_raw* ctx_lo; float* lse;
+  const float* dctx; bf16_raw* dqkv;
+  int B, S, nh, H;  // H = nh*64
+  float scale, p_drop, inv_keep; uint64_t seed;
+};
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// stage rows [0, Spad) x 64 floats of one head slice into an LDS tile (zeros beyond S)
+__device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld, int S, int Spad, int tid) {
+  for (int idx = tid; idx < Spad * 16; idx += 256) {
+    const int row = idx >> 4, c4 = idx & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < S) v = *reinterpret_cast<const float4*>(src + (long)row * ld + c4 * 4);
+    float2* d = reinterpret_cast<float2*>(dst + row * LDT + c4 * 4);
+    d[0] = make_float2(v.x, v.y);
+    d[1] = make_float2(v.z, v.w);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  constexpr int Spad = NT * 16, LDP = Spad + 2;
+  float* sK = smf;
+  float* sV = sK + Spad * LDT;
+  float* smask = sV + Spad * LDT;
+  float* wbase = smask + Spad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* sQ = wbase + wave * (16 * LDT + 16 * LDP);
+  float* sP = sQ + 16 * LDT;
+
+  const int b = blockIdx.x / p.nh, h = blockIdx.x - b * p.nh;
+  const int S = p.S;
+  const long ld = 3L * p.H;
+  const float* base = p.qkv + (long)b * S * ld + h * DH;
+  stage_rows(sK, base + p.H, ld, S, Spad, tid);
+  stage_rows(sV, base + 2 * p.H, ld, S, Spad, tid);
+  for (int k = tid; k < Spad; k += 256) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
+
+  const int nqt = (S + 15) >> 4;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  for (int it = 0; it * 4 < nqt; ++it) {
+    const int qt = it * 4 + wave;
+    const bool active = qt < nqt;
+    // this wave's 16 query rows -> its private LDS tile
+    if (active) {
+      for (int idx = lane; idx < 256; idx += 64) {
+        const int row = idx >> 4, c4 = idx & 15, q = qt * 16 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < S) v = *reinterpret_cast<const float4*>(base + (long)q * ld + c4 * 4);
+        float2* d = reinterpret_cast<float2*>(sQ + row * LDT + c4 * 4);
+        d[0] = make_float2(v.x, v.y);
+        d[1] = make_float2(v.z, v.w);
+      }
+    }
+    __syncthreads();  // K/V/mask (first trip) and this trip's Q tile are visible
+    f32x4 sc[NT];
+    if (active) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) sc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int ks = 0; ks < DH / 4; ++ks) {
+        const float a = sQ[i16 * LDT + 4 * ks + k4];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          sc[nt] = mfma4(a, sK[(nt * 16 + i16) * LDT + 4 * ks + k4], sc[nt]);
+      }
+      // softmax over the key axis (columns): each row lives on the 16 lanes sharing lane>>4
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 4 * k4 + r, q = qt * 16 + ql;
+        float m = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          sc[nt][r] = sc[nt][r] * p.scale + smask[nt * 16 + i16];
+          m = fmaxf(m, sc[nt][r]);
+        }
+        m = group16_max(m);
+        float sum = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          sc[nt][r] = __expf(sc[nt][r] - m);
+          sum += sc[nt][r];
+        }
+        sum = group16_sum(sum);
+        const float inv = 1.0f / sum;
+        if (i16 == 0 && q < S) p.lse[((long)b * p.nh + h) * S + q] = m + __logf(sum);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int key = nt * 16 + i16;
+          float pv = sc[nt][r] * inv;
+          if (p.p_drop > 0.f && q < S && key < S)
+            pv *= vl_dropout_scale(p.seed, (((uint64_t)b * p.nh + h) * S + q) * S + key, p.p_drop, p.inv_keep);
+          sP[ql * LDP + key] = pv;
+        }
+      }
+    }
+    __syncthreads();  // P tile written by all lanes of the wave
+    if (active) {
+      f32x4 o[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int ks = 0; ks < Spad / 4; ++ks) {
+        const float a = sP[i16 * LDP + 4 * ks + k4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma4(a, sV[(4 * ks + k4) * LDT + dt * 16 + i16], o[dt]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + 4 * k4 + r;
+          if (q < S) {
+            bf16_raw hi, lo;
+            split_bf16(o[dt][r], hi, lo);
+            const long off = ((long)b * S + q) * p.H + h * DH + dt * 16 + i16;
+            p.ctx_hi[off] = hi;
+            p.ctx_lo[off] = lo;
+          }
+        }
+    }
+    __syncthreads();  // before the next trip overwrites sQ / sP
+  }
+}
+
+// Backward.  dO = dctx (fp32).  Per 16-query tile (all 4 waves cooperate; wave w owns key tiles w, w+4, w+8):
+//   S = Q K^T, P = exp(S*scale + mask - LSE), dPd = dO V^T, Pd = P*D, delta = rowsum(dO*O),
+//   dS = P * (D*dPd - delta) * scale;   dV += Pd^T dO;  dK += dS^T Q;  dQ = dS K.
+// dK / dV accumulate in registers across the query tiles (no cross-workgroup reduction, no atomics).
+template <int NT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float smf[];
+  constexpr int Spad = NT * 16, LDP = Spad + 2, MAXKT = (NT + 3) / 4;
+  float* sK = smf;
+  float* sV = sK + Spad * LDT;
+  float* sQ = sV + Spad * LDT;
+  float* sdO = sQ + 16 * LDT;
+  float* sPd = sdO + 16 * LDT;
+  float* sdS = sPd + 16 * LDP;
+  float* smask = sdS + 16 * LDP;
+  float* slse = smask + Spad;
+  float* sdelta = slse + 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x - b * p.nh;
+  const int S = p.S;
+  const long ld = 3L * p.H;
+  const float* base = p.qkv + (long)b * S * ld + h * DH;
+  stage_rows(sK, base + p.H, ld, S, Spad, tid);
+  stage_rows(sV, base + 2 * p.H, ld, S, Spad, tid);
+  for (int k = tid; k < Spad; k += 256) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
+
+  f32x4 dK[MAXKT][4], dV[MAXKT][4];
+#pragma unroll
+  for (int i = 0; i < MAXKT; ++i)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dK[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[i][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nqt = (S + 15) >> 4;
+  const int i16 = lane & 15, k4 = lane >> 4;
+  for (int qt = 0; qt < nqt; ++qt) {
+    {  // 256 threads stage the 16 x 64 Q and dO tiles (one float4 each) and delta = rowsum(dO * O)
+      const int row = tid >> 4, c4 = tid & 15, q = qt * 16 + row;
+      float4 vq = make_float4(0.f, 0.f, 0.f, 0.f), vd = vq;
+      float part = 0.f;
+      if (q < S) {
+        vq = *reinterpret_cast<const float4*>(base + (long)q * ld + c4 * 4);
+        const long off = ((long)b * S + q) * p.H + h * DH + c4 * 4;
+        vd = *reinterpret_cast<const float4*>(p.dctx + off);
+        const ushort4 oh = *reinterpret_cast<const ushort4*>(p.ctx_hi + off);
+        const ushort4 ol = *reinterpret_cast<const ushort4*>(p.ctx_lo + off);
+        part = vd.x * (bf16_to_f32(oh.x) + bf16_to_f32(ol.x)) + vd.y * (bf16_to_f32(oh.y) + bf16_to_f32(ol.y)) +
+               vd.z * (bf16_to_f32(oh.z) + bf16_to_f32(ol.z)) + vd.w * (bf16_to_f32(oh.w) + bf16_to_f32(ol.w));
+      }
+      part = group16_sum(part);  // the 16 threads of a row are 16 consecutive lanes of one wave
+      float2* dq_ = reinterpret_cast<float2*>(sQ + row * LDT + c4 * 4);
+      dq_[0] = make_float2(vq.x, vq.y); dq_[1] = make_float2(vq.z, vq.w);
+      float2* dd_ = reinterpret_cast<float2*>(sdO + row * LDT + c4 * 4);
+      dd_[0] = make_float2(vd.x, vd.y); dd_[1] = make_float2(vd.z, vd.w);
+      if (c4 == 0) {
+        sdelta[row] = part;
+        slse[row] = q < S ? p.lse[((long)b * p.nh + h) * S + q] : INFINITY;  // +inf -> P = 0 for padded queries
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXKT; ++i) {
+      const int kt = wave + 4 * i;
+      if (kt < NT) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+#pragma unroll 4
+        for (int ks = 0; ks < DH / 4; ++ks) {
+          s = mfma4(sQ[i16 * LDT + 4 * ks + k4], sK[(kt * 16 + i16) * LDT + 4 * ks + k4], s);
+          dp = mfma4(sdO[i16 * LDT + 4 * ks + k4], sV[(kt * 16 + i16) * LDT + 4 * ks + k4], dp);
+        }
+        const int key = kt * 16 + i16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 4 * k4 + r, q = qt * 16 + ql;
+          const float pr = __expf(s[r] * p.scale + smask[key] - slse[ql]);
+          float dsc = 1.0f;
+          if (p.p_drop > 0.f && q < S && key < S)
+            dsc = vl_dropout_scale(p.seed, (((uint64_t)b * p.nh + h) * S + q) * S + key, p.p_drop, p.inv_keep);
+          sPd[ql * LDP + key] = pr * dsc;
+          sdS[ql * LDP + key] = pr * (dsc * dp[r] - sdelta[ql]) * p.scale;
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXKT; ++i) {
+      const int kt = wave + 4 * i;
+      if (kt < NT) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {  // 16 queries = 4 k-steps
+          const float apd = sPd[(4 * ks + k4) * LDP + kt * 16 + i16];
+          const float ads = sdS[(4 * ks + k4) * LDP + kt * 16 + i16];
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            dV[i][dt] = mfma4(apd, sdO[(4 * ks + k4) * LDT + dt * 16 + i16], dV[i][dt]);
+            dK[i][dt] = mfma4(ads, sQ[(4 * ks + k4) * LDT + dt * 16 + i16], dK[i][dt]);
+          }
+        }
+      }
+    }
+    {  // dQ tile: wave w computes head-dim columns [16w, 16w+16)
+      f32x4 dq = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+      for (int ks = 0; ks < Spad / 4; ++ks)
+        dq = mfma4(sdS[i16 * LDP + 4 * ks + k4], sK[(4 * ks + k4) * LDT + wave * 16 + i16], dq);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = qt * 16 + 4 * k4 + r;
+        if (q < S) p.dqkv[((long)b * S + q) * ld + h * DH + wave * 16 + i16] = f32_to_bf16(dq[r]);
+      }
+    }
+    __syncthreads();  // tiles are overwritten by the next trip
+  }
+#pragma unroll
+  for (int i = 0; i < MAXKT; ++i) {
+    const int kt = wave + 4 * i;
+    if (kt < NT) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * k4 + r;
+          if (key < S) {
+            const long off = ((long)b * S + key) * ld + h * DH + dt * 16 + i16;
+            p.dqkv[off + p.H] = f32_to_bf16(dK[i][dt][r]);
+            p.dqkv[off + 2 * p.H] = f32_to_bf16(dV[i][dt][r]);
+          }
+        }
+    }
+  }
+}
+
+inline size_t fwd_lds_bytes(int NT) {
+  const int Spad = NT * 16, LDP = Spad + 2;
+  return sizeof(float) * (size_t)(2 * Spad * LDT + Spad + 4 * (16 * LDT + 16 * LDP));
+}
+inline size_t bwd_lds_bytes(int NT) {
+  const int Spad = NT * 16, LDP = Spad + 2;
+  return sizeof(float) * (size_t)(2 * Spad * LDT + 2 * 16 * LDT + 2 * 16 * LDP + Spad + 32);
+}
+
+template <int NT>
+int launch_fwd(const AttnArgs& a, hipStream_t s) {
+  const size_t lds = fwd_lds_bytes(NT);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return vl_set_error(-3, "vl_attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((attn_fwd_kernel<NT>), dim3(a.B * a.nh), dim3(256), lds, s, a);
+  VL_CHECK_LAUNCH("vl_attn_fwd");
+  return 0;
+}
+template <int NT>
+int launch_bwd(const AttnArgs& a, hipStream_t s) {
+  const size_t lds = bwd_lds_bytes(NT);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return vl_set_error(-3, "vl_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((attn_bwd_kernel<NT>), dim3(a.B * a.nh), dim3(256), lds, s, a);
+  VL_CHECK_LAUNCH("vl_attn_bwd");
+  return 0;
+}
+
+int check_common(const char* fn, int64_t B, int64_t S, int64_t nh, int64_t dh, float p_drop) {
+  VL_CHECK_ARG(dh == DH, "%s: head dim must be 64 (got %lld)", fn, (long long)dh);
+  VL_CHECK_ARG(S >= 1 && S <= 160, "%s: sequence length T+V must be in [1,160] (got %lld)", fn, (long long)S);
+  VL_CHECK_ARG(B >= 1 && nh >= 1 && B * nh < (1LL << 30), "%s: bad B=%lld nh=%lld", fn, (long long)B, (long long)nh);
+  VL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: dropout p must be in [0,1)", fn);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vl_attn_fwd(const float* qkv32, const float* addmask, void* ctx_hi, void* ctx_lo, float* lse,
+                           int64_t B, int64_t S, int64_t nh, int64_t dh, float p_drop, uint64_t seed, void* stream) {
+  if (int rc = check_common("vl_attn_fwd", B, S, nh, dh, p_drop)) return rc;
+  VL_CHECK_ARG(qkv32 && addmask && ctx_hi && ctx_lo && lse, "vl_attn_fwd: null pointer");
+  AttnArgs a{};
+  a.qkv = qkv32; a.addmask = addmask; a.ctx_hi = (bf16_raw*)ctx_hi; a.ctx_lo = (bf16_raw*)ctx_lo; a.lse = lse;
+  a.B = (int)B; a.S = (int)S; a.nh = (int)nh; a.H = (int)(nh * DH);
+  a.scale = 1.0f / sqrtf((float)dh); a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+  hipStream_t s = (hipStream_t)stream;
+  if (S <= 64) return launch_fwd<4>(a, s);
+  if (S <= 80) return launch_fwd<5>(a, s);
+  if (S <= 128) return launch_fwd<8>(a, s);
+  return launch_fwd<10>(a, s);
+}
+
+extern "C" int vl_attn_bwd(const float* qkv32, const float* addmask, const void* ctx_hi, const void* ctx_lo,
+                           const float* dctx32, const float* lse, void* dqkv16, int64_t B, int64_t S, int64_t nh,
+                           int64_t dh, float p_drop, uint64_t seed, void* stream) {
+  if (int rc = check_common("vl_attn_bwd", B, S, nh, dh, p_drop)) return rc;
+  VL_CHECK_ARG(qkv32 && addmask && ctx_hi && ctx_lo && dctx32 && lse && dqkv16, "vl_attn_bwd: null pointer");
+  AttnArgs a{};
+  a.qkv = qkv32; a.addmask = addmask; a.ctx_hi = (bf16_raw*)ctx_hi; a.ctx_lo = (bf16_raw*)ctx_lo;
+  a.lse = const_cast<float*>(lse); a.dctx = dctx32; a.dqkv = (bf16_raw*)dqkv16;
+  a.B = (int)B; a.S = (int)S; a.nh = (int)nh; a.H = (int)(nh * DH);
+  a.scale = 1.0f / sqrtf((float)dh); a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop); a.seed = seed;
+  hipStream_t s = (hipStream_t)stream;
+  if (S <= 64) return launch_bwd<4>(a, s);
+  if (S <= 80) return launch_bwd<5>(a, s);
+  if (S <= 128) return launch_bwd<8>(a, s);
+  return launch_bwd<10>(a, s);
+}

@@ -1,0 +1,73 @@
+// Shared device helpers for the vlhip kernels (gfx950 / CDNA4 only: wave64, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef unsigned short bf16_raw;
+
+#define VL_WAVE 64
+
+// ---- error plumbing (host side; implemented in api.hip) -------------------------------------
+int vl_set_error(int code, const char* fmt, ...);
+#define VL_CHECK_ARG(cond, ...) do { if (!(cond)) return vl_set_error(-1, __VA_ARGS__); } while (0)
+#define VL_CHECK_LAUNCH(name) do { hipError_t e_ = hipGetLastError(); \
+    if (e_ != hipSuccess) return vl_set_error(-3, "%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
+
+// ---- bf16 helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_raw h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ bf16_raw f32_to_bf16(float f) {  // round-to-nearest-even, NaN preserved
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_raw, b);
+}
+// x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 significant bits in total.
+__device__ __forceinline__ void split_bf16(float x, bf16_raw& hi, bf16_raw& lo) {
+  hi = f32_to_bf16(x);
+  lo = f32_to_bf16(x - bf16_to_f32(hi));
+}
+
+// ---- exact-erf GELU (reference volta/encoders.py:131-137) ---------------------------------------
+__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// ---- counter-based RNG for dropout ------------------------------------------------------------
+// One 32-bit draw per (seed, stream offset, element index); the backward pass regenerates the same
+// keep-mask instead of storing it.  splitmix64-style finaliser: plenty for Bernoulli masks.
+__device__ __forceinline__ uint32_t vl_rand_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (uint32_t)(z >> 32);
+}
+// keep-scale: 1/(1-p) when kept, 0 when dropped (p == 0 -> always 1)
+__device__ __forceinline__ float vl_dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+  if (p <= 0.f) return 1.0f;
+  const float u = (float)(vl_rand_u32(seed, idx) >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.0f;
+}
+
+// ---- wave reductions (64 lanes) ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float group16_max(float v) {  // across lanes sharing lane>>4
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

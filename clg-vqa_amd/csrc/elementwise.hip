@@ -1,0 +1,400 @@
+// HBM-bound elementwise / layout kernels: sparse-fine-tuning mask products, bf16 (hi, lo) splits, weight
+// preparation, bf16 transposes, column sums, the additive attention mask, UC2 embedding gather / scatter, the
+// box-location projection, and the fused AdamW step.  All of them stream 16 B (or 8 B for bf16) per lane.
+#include "common.h"
+#include "../../include/vlhip.h"
+
+namespace {
+
+inline unsigned grid_for(int64_t work_items, int threads, int64_t cap = 256 * 8) {
+  int64_t g = (work_items + threads - 1) / threads;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+// ---- SFT: out = a (*) m  (train_task_sft.py:128-132 via torch prune.py:20-31; autograd = same product) ------
+__global__ void mask_mul_kernel(const float* __restrict__ a, const float* __restrict__ m, float* __restrict__ out,
+                                long n4, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 x = reinterpret_cast<const float4*>(a)[i];
+    const float4 y = reinterpret_cast<const float4*>(m)[i];
+    reinterpret_cast<float4*>(out)[i] = make_float4(x.x * y.x, x.y * y.y, x.z * y.z, x.w * y.w);
+  }
+  if (blockIdx.x == 0) {  // tail (n not a multiple of 4)
+    const long i = n4 * 4 + threadIdx.x;
+    if (i < n) out[i] = a[i] * m[i];
+  }
+}
+
+// ---- fp32 -> (hi, lo) bf16 split --------------------------------------------------------------------------------
+__global__ void split_kernel(const float* __restrict__ x, bf16_raw* __restrict__ hi, bf16_raw* __restrict__ lo,
+                             long n4, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    ushort4 h, l;
+    split_bf16(v.x, h.x, l.x); split_bf16(v.y, h.y, l.y); split_bf16(v.z, h.z, l.z); split_bf16(v.w, h.w, l.w);
+    reinterpret_cast<ushort4*>(hi)[i] = h;
+    if (lo) reinterpret_cast<ushort4*>(lo)[i] = l;
+  }
+  if (blockIdx.x == 0) {
+    const long i = n4 * 4 + threadIdx.x;
+    if (i < n) {
+      bf16_raw h, l;
+      split_bf16(x[i], h, l);
+      hi[i] = h;
+      if (lo) lo[i] = l;
+    }
+  }
+}
+
+// ---- weight prep: W[N,K] (*mask) -> w_hi, w_lo [N,K] (ld = ldw) and wt_hi [K,N] (ld = ldt) -------------------
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ mask,
+                                                          bf16_raw* w_hi, bf16_raw* w_lo, bf16_raw* wt_hi, int N,
+                                                          int K, long ldw, long ldt) {
+  __shared__ bf16_raw tile[64][66];
+  const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int n = n0 + rr, k = k0 + tx;
+    bf16_raw h = 0;
+    if (n < N && k < K) {
+      float v = w[(long)n * K + k];
+      if (mask) v *= mask[(long)n * K + k];
+      bf16_raw l;
+      split_bf16(v, h, l);
+      if (w_hi) w_hi[(long)n * ldw + k] = h;
+      if (w_lo) w_lo[(long)n * ldw + k] = l;
+    }
+    tile[rr][tx] = h;
+  }
+  if (!wt_hi) return;
+  __syncthreads();
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int k = k0 + rr, n = n0 + tx;
+    if (k < K && n < N) wt_hi[(long)k * ldt + n] = tile[tx][rr];
+  }
+}
+
+// ---- bf16 transpose [M,N] -> [N,M] ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_raw* __restrict__ in, bf16_raw* __restrict__ out,
+                                                        int M, int N, long ld_in, long ld_out) {
+  __shared__ bf16_raw tile[64][66];
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int m = m0 + rr, n = n0 + tx;
+    tile[rr][tx] = (m < M && n < N) ? in[(long)m * ld_in + n] : (bf16_raw)0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int n = n0 + rr, m = m0 + tx;
+    if (n < N && m < M) out[(long)n * ld_out + m] = tile[tx][rr];
+  }
+}
+
+// ---- column sums of a bf16 matrix (bias gradients) ------------------------------------------------------------
+constexpr int CS_ROWBLOCKS = 128;
+__global__ __launch_bounds__(256) void colsum_stage1(const bf16_raw* __restrict__ x, int M, int N, long ld,
+                                                     float* __restrict__ ws) {
+  __shared__ float4 red[4][64];
+  const int cg = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = (blockIdx.x * 64 + cg) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < N) {
+    for (int m = blockIdx.y * 4 + ty; m < M; m += gridDim.y * 4) {
+      const ushort4 v = *reinterpret_cast<const ushort4*>(x + (long)m * ld + n);
+      acc.x += bf16_to_f32(v.x); acc.y += bf16_to_f32(v.y); acc.z += bf16_to_f32(v.z); acc.w += bf16_to_f32(v.w);
+    }
+  }
+  red[ty][cg] = acc;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    float4 s = red[0][cg];
+    for (int t = 1; t < 4; ++t) { s.x += red[t][cg].x; s.y += red[t][cg].y; s.z += red[t][cg].z; s.w += red[t][cg].w; }
+    *reinterpret_cast<float4*>(ws + (long)blockIdx.y * N + n) = s;
+  }
+}
+__global__ void colsum_stage2(const float* __restrict__ ws, int nrb, int N, float* __restrict__ out) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < nrb; ++b) s += ws[(long)b * N + n];
+  out[n] = s;
+}
+
+// ---- additive key mask over [text ; boxes] (encoders.py:978-995) --------------------------------------------
+__global__ void addmask_kernel(const int64_t* __restrict__ tm, const int64_t* __restrict__ im, float* __restrict__ out,
+                               int B, int T, int V) {
+  const int S = T + V;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * S) return;
+  const int b = (int)(i / S), s = (int)(i - (long)b * S);
+  const float m = s < T ? (float)tm[(long)b * T + s] : (float)im[(long)b * V + (s - T)];
+  out[i] = (1.0f - m) * -10000.0f;
+}
+
+// ---- UC2 text embedding gather (embeddings.py:648-653) ---------------------------------------------------------
+__device__ __forceinline__ int roberta_pos(const int64_t* ids_row, int t, int T, int64_t pad, int lane) {
+  int cnt = 0;  // number of non-pad ids in [0, t]
+  for (int base = 0; base <= t; base += 64) {
+    const int i = base + lane;
+    const bool nz = (i <= t) && (ids_row[i] != pad);
+    cnt += __popcll(__ballot(nz));
+  }
+  return (ids_row[t] != pad ? cnt : 0) + (int)pad;
+}
+__global__ __launch_bounds__(256) void embed_text_fwd_kernel(const int64_t* __restrict__ ids,
+                                                             const int64_t* __restrict__ seg,
+                                                             const float* __restrict__ word,
+                                                             const float* __restrict__ pos,
+                                                             const float* __restrict__ type, float* __restrict__ z,
+                                                             int B, int T, int H, int64_t pad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wave;
+  if (r >= (long)B * T) return;
+  const int b = (int)(r / T), t = (int)(r - (long)b * T);
+  const int pid = roberta_pos(ids + (long)b * T, t, T, pad, lane);
+  const float* wr = word + ids[r] * (long)H;
+  const float* pr = pos + (long)pid * H;
+  const float* tr = type + seg[r] * (long)H;
+  for (int c = lane * 4; c < H; c += 256) {
+    const float4 a = *reinterpret_cast<const float4*>(wr + c);
+    const float4 d = *reinterpret_cast<const float4*>(pr + c);
+    const float4 e = *reinterpret_cast<const float4*>(tr + c);
+    *reinterpret_cast<float4*>(z + r * H + c) =
+        make_float4(a.x + d.x + e.x, a.y + d.y + e.y, a.z + d.z + e.z, a.w + d.w + e.w);
+  }
+}
+// scatter-add into the dense tables (nn.Embedding(sparse=False), embeddings.py:617); the pad row of
+// word_embeddings receives no gradient (padding_idx).  One wave per token: 256 contiguous bytes per atomic
+// wave-instruction (MI355X float-atomic sweet spot).
+__global__ __launch_bounds__(256) void embed_text_bwd_kernel(const int64_t* __restrict__ ids,
+                                                             const int64_t* __restrict__ seg,
+                                                             const float* __restrict__ dz, float* dword, float* dpos,
+                                                             float* dtype, int B, int T, int H, int64_t pad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wave;
+  if (r >= (long)B * T) return;
+  const int b = (int)(r / T), t = (int)(r - (long)b * T);
+  const int pid = roberta_pos(ids + (long)b * T, t, T, pad, lane);
+  const int64_t id = ids[r];
+  float* wr = dword + id * (long)H;
+  float* pr = dpos + (long)pid * H;
+  float* tr = dtype + seg[r] * (long)H;
+  for (int c = lane; c < H; c += 64) {
+    const float g = dz[r * H + c];
+    if (id != pad) atomicAdd(wr + c, g);
+    atomicAdd(pr + c, g);
+    atomicAdd(tr + c, g);
+  }
+}
+
+// ---- box-location projection (embeddings.py:661: Linear(num_locs -> H)) ---------------------------------------
+__global__ void loc_fwd_kernel(const float* __restrict__ loc, const float* __restrict__ w, const float* __restrict__ b,
+                               float* __restrict__ y, long R, int L, int H) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * H) return;
+  const long r = i / H;
+  const int c = (int)(i - r * H);
+  float s = b[c];
+  for (int l = 0; l < L; ++l) s += loc[r * L + l] * w[c * L + l];
+  y[i] = s;
+}
+__global__ __launch_bounds__(256) void loc_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ dy,
+                                                      float* dw, float* db, long R, int L, int H) {
+  const long r0 = (long)blockIdx.x * 64;
+  const long r1 = r0 + 64 < R ? r0 + 64 : R;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    for (long r = r0; r < r1; ++r) {
+      const float g = dy[r * H + c];
+      accb += g;
+#pragma unroll
+      for (int l = 0; l < 8; ++l)
+        if (l < L) acc[l] += g * loc[r * L + l];
+    }
+    atomicAdd(db + c, accb);
+#pragma unroll
+    for (int l = 0; l < 8; ++l)
+      if (l < L) atomicAdd(dw + c * L + l, acc[l]);
+  }
+}
+
+// ---- fused AdamW over a flat arena ---------------------------------------------------------------------------
+// pytorch_transformers.optimization.AdamW semantics (un-vendored dependency of the reference; call site
+// train_task.py:264-268): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= step * m / (sqrt(v) + eps) with
+// step = lr (* sqrt(1-b2^t)/(1-b1^t) when correct_bias); then decoupled decay p -= lr * wd * p.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n,
+                                                    const int64_t* __restrict__ seg_end,
+                                                    const float* __restrict__ seg_lr,
+                                                    const float* __restrict__ seg_wd, int nseg, float b1, float b2,
+                                                    float eps, float bc, float lr_mult, const float* gscale_ptr,
+                                                    float gscale_const, int zero_grad) {
+  const float gs = gscale_ptr ? *gscale_ptr : gscale_const;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int lo = 0, hi = nseg - 1;  // first segment whose end > i
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (seg_end[mid] > i) hi = mid; else lo = mid + 1;
+    }
+    const float lr = seg_lr[lo] * lr_mult, wd = seg_wd[lo];
+    const float grad = g[i] * gs;
+    const float mi = b1 * m[i] + (1.f - b1) * grad;
+    const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
+    m[i] = mi; v[i] = vi;
+    float x = p[i] - (lr * bc) * (mi / (sqrtf(vi) + eps));
+    if (wd > 0.f) x -= lr * wd * x;
+    p[i] = x;
+    if (zero_grad) g[i] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+}  // namespace
+
+extern "C" int vl_mask_mul(const float* a, const float* m, float* out, int64_t n, void* stream) {
+  VL_CHECK_ARG(a && m && out && n >= 0, "vl_mask_mul: bad arguments");
+  if (n == 0) return 0;
+  VL_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)m & 15) == 0 && ((uintptr_t)out & 15) == 0,
+               "vl_mask_mul: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, m, out,
+                     (long)(n / 4), (long)n);
+  VL_CHECK_LAUNCH("vl_mask_mul");
+  return 0;
+}
+
+extern "C" int vl_split_f32(const float* x32, void* hi, void* lo, int64_t n, void* stream) {
+  VL_CHECK_ARG(x32 && hi && n >= 0, "vl_split_f32: bad arguments");
+  if (n == 0) return 0;
+  VL_CHECK_ARG(((uintptr_t)x32 & 15) == 0 && ((uintptr_t)hi & 7) == 0 && ((uintptr_t)lo & 7) == 0,
+               "vl_split_f32: misaligned pointers");
+  hipLaunchKernelGGL(split_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, x32,
+                     (bf16_raw*)hi, (bf16_raw*)lo, (long)(n / 4), (long)n);
+  VL_CHECK_LAUNCH("vl_split_f32");
+  return 0;
+}
+
+extern "C" int vl_weight_prep(const float* w32, const float* mask32, void* w_hi, void* w_lo, void* wt_hi, int64_t N,
+                              int64_t K, int64_t ldw, int64_t ldt, void* stream) {
+  VL_CHECK_ARG(w32 && N > 0 && K > 0 && (w_hi || w_lo || wt_hi), "vl_weight_prep: bad arguments");
+  VL_CHECK_ARG(ldw >= K && (!wt_hi || ldt >= N), "vl_weight_prep: leading dimensions too small");
+  hipLaunchKernelGGL(weight_prep_kernel, dim3((unsigned)((K + 63) / 64), (unsigned)((N + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, w32, mask32, (bf16_raw*)w_hi, (bf16_raw*)w_lo, (bf16_raw*)wt_hi, (int)N,
+                     (int)K, (long)ldw, (long)ldt);
+  VL_CHECK_LAUNCH("vl_weight_prep");
+  return 0;
+}
+
+extern "C" int vl_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t ld_out,
+                                 void* stream) {
+  VL_CHECK_ARG(in && out && M > 0 && N > 0 && ld_in >= N && ld_out >= M, "vl_transpose_bf16: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_raw*)in, (bf16_raw*)out, (int)M, (int)N, (long)ld_in,
+                     (long)ld_out);
+  VL_CHECK_LAUNCH("vl_transpose_bf16");
+  return 0;
+}
+
+extern "C" int64_t vl_colsum_ws_floats(int64_t M, int64_t N) {
+  int64_t rb = (M + 3) / 4;
+  if (rb > CS_ROWBLOCKS) rb = CS_ROWBLOCKS;
+  return rb * N;
+}
+extern "C" int vl_colsum_bf16(const void* x16, int64_t M, int64_t N, int64_t ld, float* ws, float* out32,
+                              void* stream) {
+  VL_CHECK_ARG(x16 && ws && out32 && M > 0 && N > 0, "vl_colsum_bf16: bad arguments");
+  VL_CHECK_ARG(N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x16 & 7) == 0, "vl_colsum_bf16: N, ld must be multiples of 4");
+  int64_t rb = (M + 3) / 4;
+  if (rb > CS_ROWBLOCKS) rb = CS_ROWBLOCKS;
+  hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)((N + 255) / 256), (unsigned)rb), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_raw*)x16, (int)M, (int)N, (long)ld, ws);
+  VL_CHECK_LAUNCH("vl_colsum_bf16");
+  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, (int)rb,
+                     (int)N, out32);
+  VL_CHECK_LAUNCH("vl_colsum_bf16(stage2)");
+  return 0;
+}
+
+extern "C" int vl_addmask(const int64_t* text_mask, const int64_t* img_mask, float* addmask, int64_t B, int64_t T,
+                          int64_t V, void* stream) {
+  VL_CHECK_ARG(text_mask && img_mask && addmask && B > 0 && T > 0 && V > 0, "vl_addmask: bad arguments");
+  const int64_t n = B * (T + V);
+  hipLaunchKernelGGL(addmask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, text_mask,
+                     img_mask, addmask, (int)B, (int)T, (int)V);
+  VL_CHECK_LAUNCH("vl_addmask");
+  return 0;
+}
+
+extern "C" int vl_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
+                                 const float* type, float* z32, int64_t B, int64_t T, int64_t H, int64_t pad_id,
+                                 void* stream) {
+  VL_CHECK_ARG(ids && seg && word && pos && type && z32 && B > 0 && T > 0 && H > 0 && H % 4 == 0,
+               "vl_embed_text_fwd: bad arguments (H must be a multiple of 4)");
+  hipLaunchKernelGGL(embed_text_fwd_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
+                     seg, word, pos, type, z32, (int)B, (int)T, (int)H, pad_id);
+  VL_CHECK_LAUNCH("vl_embed_text_fwd");
+  return 0;
+}
+extern "C" int vl_embed_text_bwd(const int64_t* ids, const int64_t* seg, const float* dz32, float* dword, float* dpos,
+                                 float* dtype, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream) {
+  VL_CHECK_ARG(ids && seg && dz32 && dword && dpos && dtype && B > 0 && T > 0 && H > 0, "vl_embed_text_bwd: bad arguments");
+  hipLaunchKernelGGL(embed_text_bwd_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
+                     seg, dz32, dword, dpos, dtype, (int)B, (int)T, (int)H, pad_id);
+  VL_CHECK_LAUNCH("vl_embed_text_bwd");
+  return 0;
+}
+
+extern "C" int vl_loc_linear_fwd(const float* loc, const float* w, const float* b, float* y32, int64_t R, int64_t L,
+                                 int64_t H, void* stream) {
+  VL_CHECK_ARG(loc && w && b && y32 && R > 0 && L > 0 && L <= 8 && H > 0, "vl_loc_linear_fwd: bad arguments (L <= 8)");
+  hipLaunchKernelGGL(loc_fwd_kernel, dim3((unsigned)((R * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream, loc, w,
+                     b, y32, (long)R, (int)L, (int)H);
+  VL_CHECK_LAUNCH("vl_loc_linear_fwd");
+  return 0;
+}
+extern "C" int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db, int64_t R, int64_t L,
+                                 int64_t H, void* stream) {
+  VL_CHECK_ARG(loc && dy32 && dw && db && R > 0 && L > 0 && L <= 8 && H > 0, "vl_loc_linear_bwd: bad arguments (L <= 8)");
+  hipLaunchKernelGGL(loc_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream, loc, dy32, dw,
+                     db, (long)R, (int)L, (int)H);
+  VL_CHECK_LAUNCH("vl_loc_linear_bwd");
+  return 0;
+}
+
+extern "C" int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1,
+                        float beta2, float eps, int64_t step, int correct_bias, float lr_mult,
+                        const float* grad_scale_dev, float grad_scale, int zero_grad, void* stream) {
+  VL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && seg_end && seg_lr && seg_wd && n > 0 && nseg > 0 && step > 0,
+               "vl_adamw: bad arguments");
+  float bc = 1.0f;
+  if (correct_bias) bc = (float)(sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step)));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, (long)n, seg_end, seg_lr, seg_wd, (int)nseg, beta1, beta2, eps, bc, lr_mult,
+                     grad_scale_dev, grad_scale, zero_grad);
+  VL_CHECK_LAUNCH("vl_adamw");
+  return 0;
+}
+
+extern "C" int vl_sumsq(const float* x, int64_t n, float* out, void* stream) {
+  VL_CHECK_ARG(x && out && n > 0, "vl_sumsq: bad arguments");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+  VL_CHECK_LAUNCH("vl_sumsq");
+  return 0;
+}

@@ -1,0 +1,273 @@
+// vl_ln_fwd / vl_ln_bwd: (dropout +) residual + LayerNorm with wavefront reductions.
+//
+// Reference: BertLayerNorm = apex FusedLayerNorm when built (volta/volta/encoders.py:44-47; CUDA kernels
+// volta/apex/csrc/layer_norm_cuda_kernel.cu:279-322 cuApplyLayerNorm, :403-520 cuComputePartGradGammaBeta /
+// cuComputeGradGammaBeta, :522-637 cuComputeGradInput) else the TF-style Python module (encoders.py:49-62):
+// biased variance, epsilon inside the sqrt.  Fused here with the eager ops around it in
+// BertGatedSelfOutput / BertGatedOutput (encoders.py:411-425, :553-567: dropout(dense) + input -> LN) and in
+// UC2Embeddings (embeddings.py:653-666: LN -> dropout; sum of three terms -> LN).
+//
+// HBM-bound: one wave64 per row, the row (H = NV*256 floats) lives in registers as NV float4 per lane, mean
+// and variance are two wave reductions (two-pass, like the reference), all traffic is 16 B per lane.
+// Backward keeps per-lane column partials (dgamma, dbeta, dbias) in registers across the rows a wave walks,
+// then one LDS combine per workgroup and a second tiny kernel sums the per-workgroup partials (deterministic;
+// no atomics).
+#include "common.h"
+#include "../../include/vlhip.h"
+
+namespace {
+
+constexpr uint64_t POST_SALT = 0x5bd1e9955bd1e995ull;
+
+struct LnArgs {
+  float* y; const float* resid; const float* addvec; const float* gamma; const float* beta; float eps;
+  float* out32; bf16_raw* out_hi; bf16_raw* out_lo; float* mean; float* rstd;
+  long M; int H; long group, out_stride, out_off;
+  float p_pre, inv_pre, p_post, inv_post; uint64_t seed;
+  // backward
+  const float* dy; const float* z; float* dz; bf16_raw* dpre16; float* dpre32; float* ws; int nblk;
+};
+
+__device__ __forceinline__ long map_row(const LnArgs& p, long r) {
+  return (r / p.group) * p.out_stride + p.out_off + (r % p.group);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invH = 1.0f / (float)p.H;
+  for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4) {
+    float4 z[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const long e = r * p.H + c;
+      float4 v = *reinterpret_cast<const float4*>(p.y + e);
+      if (p.p_pre > 0.f) {
+        v.x *= vl_dropout_scale(p.seed, e + 0, p.p_pre, p.inv_pre);
+        v.y *= vl_dropout_scale(p.seed, e + 1, p.p_pre, p.inv_pre);
+        v.z *= vl_dropout_scale(p.seed, e + 2, p.p_pre, p.inv_pre);
+        v.w *= vl_dropout_scale(p.seed, e + 3, p.p_pre, p.inv_pre);
+      }
+      if (p.resid) {
+        const float4 q = *reinterpret_cast<const float4*>(p.resid + e);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      if (p.addvec) {
+        const float4 q = *reinterpret_cast<const float4*>(p.addvec + c);
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      }
+      if (p.p_pre > 0.f || p.resid || p.addvec) *reinterpret_cast<float4*>(p.y + e) = v;  // z saved in place
+      z[i] = v;
+      s += (v.x + v.y) + (v.z + v.w);
+    }
+    const float mu = wave_sum(s) * invH;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float a = z[i].x - mu, b = z[i].y - mu, c = z[i].z - mu, d = z[i].w - mu;
+      ss += (a * a + b * b) + (c * c + d * d);
+    }
+    const float rs = 1.0f / sqrtf(wave_sum(ss) * invH + p.eps);
+    if (lane == 0) { p.mean[r] = mu; p.rstd[r] = rs; }
+    const long orow = map_row(p, r);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
+      const float4 bt = *reinterpret_cast<const float4*>(p.beta + c);
+      float4 o;
+      o.x = g.x * ((z[i].x - mu) * rs) + bt.x;
+      o.y = g.y * ((z[i].y - mu) * rs) + bt.y;
+      o.z = g.z * ((z[i].z - mu) * rs) + bt.z;
+      o.w = g.w * ((z[i].w - mu) * rs) + bt.w;
+      if (p.p_post > 0.f) {
+        const long e = r * p.H + c;
+        o.x *= vl_dropout_scale(p.seed ^ POST_SALT, e + 0, p.p_post, p.inv_post);
+        o.y *= vl_dropout_scale(p.seed ^ POST_SALT, e + 1, p.p_post, p.inv_post);
+        o.z *= vl_dropout_scale(p.seed ^ POST_SALT, e + 2, p.p_post, p.inv_post);
+        o.w *= vl_dropout_scale(p.seed ^ POST_SALT, e + 3, p.p_post, p.inv_post);
+      }
+      const long eo = orow * p.H + c;
+      if (p.out32) *reinterpret_cast<float4*>(p.out32 + eo) = o;
+      if (p.out_hi) {
+        ushort4 hi, lo;
+        split_bf16(o.x, hi.x, lo.x); split_bf16(o.y, hi.y, lo.y);
+        split_bf16(o.z, hi.z, lo.z); split_bf16(o.w, hi.w, lo.w);
+        *reinterpret_cast<ushort4*>(p.out_hi + eo) = hi;
+        if (p.out_lo) *reinterpret_cast<ushort4*>(p.out_lo + eo) = lo;
+      }
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
+  __shared__ float red[3][4][NV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invH = 1.0f / (float)p.H;
+  float4 ag[NV], ab[NV], ap[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ap[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4) {
+    const long orow = map_row(p, r);
+    const float mu = p.mean[r], rs = p.rstd[r];
+    float4 dy[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const long e = r * p.H + c;
+      float4 d = *reinterpret_cast<const float4*>(p.dy + orow * p.H + c);
+      if (p.p_post > 0.f) {
+        d.x *= vl_dropout_scale(p.seed ^ POST_SALT, e + 0, p.p_post, p.inv_post);
+        d.y *= vl_dropout_scale(p.seed ^ POST_SALT, e + 1, p.p_post, p.inv_post);
+        d.z *= vl_dropout_scale(p.seed ^ POST_SALT, e + 2, p.p_post, p.inv_post);
+        d.w *= vl_dropout_scale(p.seed ^ POST_SALT, e + 3, p.p_post, p.inv_post);
+      }
+      const float4 zz = *reinterpret_cast<const float4*>(p.z + e);
+      const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
+      float4 x;
+      x.x = (zz.x - mu) * rs; x.y = (zz.y - mu) * rs; x.z = (zz.z - mu) * rs; x.w = (zz.w - mu) * rs;
+      ag[i].x += d.x * x.x; ag[i].y += d.y * x.y; ag[i].z += d.z * x.z; ag[i].w += d.w * x.w;
+      ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+      d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;  // now dL/dxhat
+      s1 += (d.x + d.y) + (d.z + d.w);
+      s2 += (d.x * x.x + d.y * x.y) + (d.z * x.z + d.w * x.w);
+      dy[i] = d; xh[i] = x;
+    }
+    const float c1 = wave_sum(s1) * invH, c2 = wave_sum(s2) * invH;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const long e = r * p.H + c;
+      float4 dz;
+      dz.x = (dy[i].x - c1 - xh[i].x * c2) * rs;
+      dz.y = (dy[i].y - c1 - xh[i].y * c2) * rs;
+      dz.z = (dy[i].z - c1 - xh[i].z * c2) * rs;
+      dz.w = (dy[i].w - c1 - xh[i].w * c2) * rs;
+      if (p.dz) *reinterpret_cast<float4*>(p.dz + e) = dz;
+      float4 dp = dz;
+      if (p.p_pre > 0.f) {
+        dp.x *= vl_dropout_scale(p.seed, e + 0, p.p_pre, p.inv_pre);
+        dp.y *= vl_dropout_scale(p.seed, e + 1, p.p_pre, p.inv_pre);
+        dp.z *= vl_dropout_scale(p.seed, e + 2, p.p_pre, p.inv_pre);
+        dp.w *= vl_dropout_scale(p.seed, e + 3, p.p_pre, p.inv_pre);
+      }
+      if (p.dpre32) *reinterpret_cast<float4*>(p.dpre32 + e) = dp;
+      if (p.dpre16) {
+        ushort4 h;
+        h.x = f32_to_bf16(dp.x); h.y = f32_to_bf16(dp.y); h.z = f32_to_bf16(dp.z); h.w = f32_to_bf16(dp.w);
+        *reinterpret_cast<ushort4*>(p.dpre16 + e) = h;
+      }
+      ap[i].x += dp.x; ap[i].y += dp.y; ap[i].z += dp.z; ap[i].w += dp.w;
+    }
+  }
+  // combine the 4 waves' column partials, then one partial row-set per workgroup
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    *reinterpret_cast<float4*>(&red[0][wave][c]) = ag[i];
+    *reinterpret_cast<float4*>(&red[1][wave][c]) = ab[i];
+    *reinterpret_cast<float4*>(&red[2][wave][c]) = ap[i];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 3 * p.H; idx += 256) {
+    const int k = idx / p.H, c = idx - k * p.H;
+    p.ws[((long)blockIdx.x * 3 + k) * p.H + c] = (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]);
+  }
+}
+
+// out_k[c] = sum_blk ws[blk][k][c]
+__global__ void ln_bwd_reduce_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta, float* dbias) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= 3 * H) return;
+  const int k = idx / H, c = idx - k * H;
+  float* dst = k == 0 ? dgamma : (k == 1 ? dbeta : dbias);
+  if (!dst) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += ws[((long)b * 3 + k) * H + c];
+  dst[c] = s;
+}
+
+int nblk_for(int64_t M) {
+  int64_t n = (M + 3) / 4;
+  return (int)(n < 512 ? n : 512);
+}
+
+template <int NV>
+int launch_fwd(const LnArgs& a, hipStream_t s) {
+  int64_t n = (a.M + 3) / 4;
+  if (n > 4096) n = 4096;
+  hipLaunchKernelGGL((ln_fwd_kernel<NV>), dim3((unsigned)n), dim3(256), 0, s, a);
+  VL_CHECK_LAUNCH("vl_ln_fwd");
+  return 0;
+}
+template <int NV>
+int launch_bwd(const LnArgs& a, hipStream_t s, float* dgamma, float* dbeta, float* dbias) {
+  hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(a.nblk), dim3(256), 0, s, a);
+  VL_CHECK_LAUNCH("vl_ln_bwd");
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * a.H + 255) / 256), dim3(256), 0, s, a.ws, a.nblk, a.H,
+                     dgamma, dbeta, dbias);
+  VL_CHECK_LAUNCH("vl_ln_bwd(reduce)");
+  return 0;
+}
+
+int check_shape(const char* fn, int64_t M, int64_t H, int64_t group, float p_pre, float p_post) {
+  VL_CHECK_ARG(M > 0 && H > 0 && H % 256 == 0 && H <= 2048 && (H / 256 <= 4 || H == 1536 || H == 2048),
+               "%s: H must be 256,512,768,1024,1536 or 2048 (got %lld)", fn, (long long)H);
+  VL_CHECK_ARG(group > 0, "%s: group must be > 0", fn);
+  VL_CHECK_ARG(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "%s: dropout p must be in [0,1)", fn);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, const float* gamma,
+                         const float* beta, float eps, float* out32, void* out_hi, void* out_lo, float* mean,
+                         float* rstd, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
+                         float p_pre, float p_post, uint64_t seed, void* stream) {
+  if (int rc = check_shape("vl_ln_fwd", M, H, group, p_pre, p_post)) return rc;
+  VL_CHECK_ARG(y32_z32 && gamma && beta && mean && rstd && (out32 || out_hi), "vl_ln_fwd: null pointer");
+  LnArgs a{};
+  a.y = y32_z32; a.resid = resid32; a.addvec = addvec; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  a.out32 = out32; a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.mean = mean; a.rstd = rstd;
+  a.M = M; a.H = (int)H; a.group = group; a.out_stride = out_stride; a.out_off = out_off;
+  a.p_pre = p_pre; a.inv_pre = 1.f / (1.f - p_pre); a.p_post = p_post; a.inv_post = 1.f / (1.f - p_post);
+  a.seed = seed;
+  hipStream_t s = (hipStream_t)stream;
+  switch (H / 256) {
+    case 1: return launch_fwd<1>(a, s);
+    case 2: return launch_fwd<2>(a, s);
+    case 3: return launch_fwd<3>(a, s);
+    case 4: return launch_fwd<4>(a, s);
+    case 6: return launch_fwd<6>(a, s);
+    default: return launch_fwd<8>(a, s);
+  }
+}
+
+extern "C" int64_t vl_ln_bwd_ws_floats(int64_t M, int64_t H) { return (int64_t)nblk_for(M) * 3 * H; }
+
+extern "C" int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd,
+                         const float* gamma, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta,
+                         float* dbias, float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride,
+                         int64_t out_off, float p_pre, float p_post, uint64_t seed, void* stream) {
+  if (int rc = check_shape("vl_ln_bwd", M, H, group, p_pre, p_post)) return rc;
+  VL_CHECK_ARG(dy32 && z32 && mean && rstd && gamma && partial_ws, "vl_ln_bwd: null pointer");
+  LnArgs a{};
+  a.dy = dy32; a.z = z32; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.gamma = gamma;
+  a.dz = dz32; a.dpre16 = (bf16_raw*)dpre16; a.dpre32 = dpre32; a.ws = partial_ws; a.nblk = nblk_for(M);
+  a.M = M; a.H = (int)H; a.group = group; a.out_stride = out_stride; a.out_off = out_off;
+  a.p_pre = p_pre; a.inv_pre = 1.f / (1.f - p_pre); a.p_post = p_post; a.inv_post = 1.f / (1.f - p_post);
+  a.seed = seed;
+  hipStream_t s = (hipStream_t)stream;
+  switch (H / 256) {
+    case 1: return launch_bwd<1>(a, s, dgamma, dbeta, dbias);
+    case 2: return launch_bwd<2>(a, s, dgamma, dbeta, dbias);
+    case 3: return launch_bwd<3>(a, s, dgamma, dbeta, dbias);
+    case 4: return launch_bwd<4>(a, s, dgamma, dbeta, dbias);
+    case 6: return launch_bwd<6>(a, s, dgamma, dbeta, dbias);
+    default: return launch_bwd<8>(a, s, dgamma, dbeta, dbias);
+  }
+}

@@ -1,0 +1,362 @@
+"""Host-side orchestration of the native UC2 trunk (embeddings + 12 x {attention, feed-forward}).
+
+One ``torch.autograd.Function`` covers the whole trunk: its forward enqueues the HIP kernels of
+``include/vlhip.h`` on the current stream and keeps the activations the backward needs; its backward enqueues
+the backward kernels and returns the parameter gradients.  torch is used for device memory, the stream and the
+autograd hand-off at the trunk's output only.
+
+Reference call stack restated here: BertModel.forward (volta/volta/encoders.py:958-1021) ->
+UC2Embeddings.forward (volta/volta/embeddings.py:636-669) -> BertEncoder.forward (encoders.py:848-892) ->
+24 x {BertGatedAttention :434 | BertGatedFeedForward :576}, in the single-stream form of SURVEY.md Appendix A.
+
+Data layout in HBM (B = batch, T text tokens, V boxes, S = T + V, M = B*S rows, H hidden, I intermediate):
+  stream  x32 [M,H] fp32 (residual stream) + (x_hi, x_lo) bf16 split feeding the 3-pass forward GEMMs
+  qkv32   [M,3H] fp32, columns [Q|K|V]             ctx (hi,lo) [M,H] bf16
+  u16/h   [M,I] bf16 pre-activation / GELU output  weights: (hi,lo) [N,K] + transposed hi [K,N], rebuilt per step
+"""
+import torch
+
+from . import ops
+from .ops import BF16, EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_SPLIT
+
+
+def _ceil8(n):
+    return (n + 7) // 8 * 8
+
+
+def linear_params(lin):
+    """(differentiable weight, mask or None) of a leaf Linear, honouring torch.nn.utils.prune's
+    reparametrisation (weight_orig / weight_mask) that the reference's SFT driver installs by module name
+    (volta/train_task_sft.py:122-132)."""
+    if "weight_orig" in lin._parameters:
+        return lin._parameters["weight_orig"], lin._buffers["weight_mask"]
+    return lin.weight, None
+
+
+class PreparedWeight(object):
+    """bf16 operand forms of one (possibly packed) Linear weight: (hi, lo) [N,K] and transposed hi [K,Np]."""
+
+    def __init__(self, linears, device, need_t=True):
+        self.linears = linears
+        self.N = sum(l.out_features for l in linears)
+        self.K = linears[0].in_features
+        self.Np = _ceil8(self.N)
+        self.hi = torch.empty(self.N, self.K, dtype=BF16, device=device)
+        self.lo = torch.empty(self.N, self.K, dtype=BF16, device=device)
+        self.t_hi = torch.zeros(self.K, self.Np, dtype=BF16, device=device) if need_t else None
+        self.bias = None
+        self.key = None
+
+    def _key(self):
+        k = []
+        for l in self.linears:
+            w, m = linear_params(l)
+            k.append((w.data_ptr(), w._version, None if m is None else (m.data_ptr(), m._version),
+                      l.bias.data_ptr(), l.bias._version))
+        return tuple(k)
+
+    def refresh(self, force=False):
+        key = self._key()
+        if not force and key == self.key:
+            return
+        r = 0
+        for l in self.linears:
+            w, m = linear_params(l)
+            n = l.out_features
+            ops.weight_prep(w.detach(), m, self.hi[r:r + n], self.lo[r:r + n],
+                            None if self.t_hi is None else self.t_hi[:, r:r + n])
+            r += n
+        self.bias = (self.linears[0].bias.detach() if len(self.linears) == 1
+                     else torch.cat([l.bias.detach() for l in self.linears]))
+        self.key = key
+
+
+def dw_gemm(dy16, x16, M, N, K):
+    """dW[N,K] = dY[M,N]^T . X[M,K] (bf16 operands, fp32 out) as an NT GEMM over transposed copies."""
+    dev = dy16.device
+    Mp = _ceil8(M)
+    alloc = torch.zeros if Mp != M else torch.empty
+    dyT = alloc(N, Mp, dtype=BF16, device=dev)
+    xT = alloc(K, Mp, dtype=BF16, device=dev)
+    ops.transpose_bf16(dy16, dyT, M, N)
+    ops.transpose_bf16(x16, xT, M, K)
+    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+    ops.gemm_nt(dyT, None, xT, None, N, K, Mp, 1, EPI_F32, out32=dW)
+    return dW
+
+
+class UC2Engine(object):
+    """Binds a ``BertForVLTasks`` module tree (reference parameter names) to the native kernels."""
+
+    def __init__(self, model):
+        self.model = model
+        cfg = model.config
+        self.H = cfg.hidden_size
+        self.nh = cfg.num_attention_heads
+        self.I = cfg.intermediate_size
+        self.eps = cfg.layer_norm_eps
+        self.n_layers = len(model.bert.encoder.layer) // 2
+        if self.H % self.nh != 0 or self.H // self.nh != 64:
+            raise ValueError("clg_vqa_amd: the native attention kernel needs head dim 64 (hidden %d / heads %d)"
+                             % (self.H, self.nh))
+        if self.H % 256 != 0:
+            raise ValueError("clg_vqa_amd: hidden size must be a multiple of 256 for the native LayerNorm")
+        self._prepared = None
+        self._dirty = True
+        self.base_seed = 0x5EED
+        self.calls = 0
+
+    # ---- parameters ------------------------------------------------------------------------------------------
+    def param_list(self):
+        """Differentiable tensors of the trunk in a fixed order (backward returns grads in this order)."""
+        e = self.model.bert.embeddings
+        ps = [e.word_embeddings.weight, e.position_embeddings.weight, e.new_token_type_embeddings.weight,
+              e.LayerNorm.weight, e.LayerNorm.bias, linear_params(e.image_embeddings)[0], e.image_embeddings.bias,
+              e.image_location_embeddings.weight, e.image_location_embeddings.bias,
+              e.image_layer_norm.weight, e.image_layer_norm.bias,
+              e.image_location_layer_norm.weight, e.image_location_layer_norm.bias,
+              e.v_LayerNorm.weight, e.v_LayerNorm.bias]
+        for l in range(self.n_layers):
+            at = self.model.bert.encoder.layer[2 * l]
+            ff = self.model.bert.encoder.layer[2 * l + 1]
+            sa, so = at.attention_self, at.attention_output
+            for lin in (sa.query, sa.key, sa.value, so.dense):
+                ps += [linear_params(lin)[0], lin.bias]
+            ps += [so.LayerNorm.weight, so.LayerNorm.bias]
+            for lin in (ff.intermediate.dense, ff.output.dense):
+                ps += [linear_params(lin)[0], lin.bias]
+            ps += [ff.output.LayerNorm.weight, ff.output.LayerNorm.bias]
+        return ps
+
+    def mark_dirty(self):
+        """Call after updating parameters through raw pointers (the fused optimizer does)."""
+        self._dirty = True
+
+    def prepared(self, device):
+        if self._prepared is None or self._prepared["device"] != device:
+            e = self.model.bert.embeddings
+            layers = []
+            for l in range(self.n_layers):
+                at = self.model.bert.encoder.layer[2 * l]
+                ff = self.model.bert.encoder.layer[2 * l + 1]
+                sa = at.attention_self
+                layers.append(dict(
+                    qkv=PreparedWeight([sa.query, sa.key, sa.value], device),
+                    o=PreparedWeight([at.attention_output.dense], device),
+                    w1=PreparedWeight([ff.intermediate.dense], device),
+                    w2=PreparedWeight([ff.output.dense], device)))
+            self._prepared = dict(device=device, img=PreparedWeight([e.image_embeddings], device, need_t=False),
+                                  layers=layers)
+            self._dirty = True
+        pw = self._prepared
+        force = self._dirty
+        pw["img"].refresh(force)
+        for lw in pw["layers"]:
+            for k in ("qkv", "o", "w1", "w2"):
+                lw[k].refresh(force)
+        self._dirty = False
+        return pw
+
+    # ---- forward -------------------------------------------------------------------------------------------------
+    def forward(self, ids, feats, locs, seg, tmask, imask, training):
+        cfg = self.model.config
+        emb = self.model.bert.embeddings
+        dev = feats.device
+        if not feats.is_cuda:
+            raise RuntimeError("clg_vqa_amd: BertForVLTasks runs on the MI355X only (no CPU path); move the model "
+                               "and the batch to a cuda/HIP device")
+        B, T = ids.shape
+        V, F = feats.shape[1], feats.shape[2]
+        L = locs.shape[2]
+        S, H, I, nh = T + V, self.H, self.I, self.nh
+        M, BT, BV = B * S, B * T, B * V
+        p_hid = float(cfg.hidden_dropout_prob) if training else 0.0
+        p_att = float(cfg.attention_probs_dropout_prob) if training else 0.0
+        self.calls += 1
+        seed0 = (self.base_seed * 0x9E3779B1 + self.calls * 0x10001) & 0x7FFFFFFFFFFF
+        seed = lambda site: (seed0 * 4096 + site) & 0xFFFFFFFFFFFFFFFF  # noqa: E731
+        pw = self.prepared(dev)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
+        ids = ids.contiguous(); seg = seg.contiguous()
+        tmask = tmask.contiguous().to(torch.int64); imask = imask.contiguous().to(torch.int64)
+        feats2 = feats.contiguous().view(BV, F)
+        locs2 = locs.contiguous().view(BV, L)
+        sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, ids=ids, seg=seg,
+                  locs=locs2, pw=pw, layers=[])
+
+        am = f32(M)
+        ops.addmask(tmask, imask, am, B, T, V)
+        sv["am"] = am
+
+        x32, x_hi, x_lo = f32(M, H), b16(M, H), b16(M, H)
+        # text rows: word + position + type -> LN -> dropout   (embeddings.py:648-655)
+        z_t, mean_t, rstd_t = f32(BT, H), f32(BT), f32(BT)
+        type_w = emb.new_token_type_embeddings.weight.detach()
+        ops.embed_text_fwd(ids, seg, emb.word_embeddings.weight.detach(), emb.position_embeddings.weight.detach(),
+                           type_w, z_t, B, T, H, int(cfg.pad_token_id))
+        ops.ln_fwd(z_t, None, None, emb.LayerNorm.weight.detach(), emb.LayerNorm.bias.detach(), self.eps, x32, x_hi,
+                   x_lo, mean_t, rstd_t, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
+        # box rows: LN(feat W^T + b) + LN(loc W^T + b) + type[1] -> LN -> dropout   (embeddings.py:660-667)
+        f_hi, f_lo = b16(BV, F), b16(BV, F)
+        ops.split_f32(feats2, f_hi, f_lo)
+        z_i, mean_i, rstd_i, a32 = f32(BV, H), f32(BV), f32(BV), f32(BV, H)
+        ops.gemm_nt(f_hi, f_lo, pw["img"].hi, pw["img"].lo, BV, H, F, 3, EPI_F32, bias=pw["img"].bias, out32=z_i)
+        ops.ln_fwd(z_i, None, None, emb.image_layer_norm.weight.detach(), emb.image_layer_norm.bias.detach(),
+                   self.eps, a32, None, None, mean_i, rstd_i, BV, H)
+        z_l, mean_l, rstd_l, b32 = f32(BV, H), f32(BV), f32(BV), f32(BV, H)
+        ops.loc_linear_fwd(locs2, emb.image_location_embeddings.weight.detach(),
+                           emb.image_location_embeddings.bias.detach(), z_l, BV, L, H)
+        ops.ln_fwd(z_l, None, None, emb.image_location_layer_norm.weight.detach(),
+                   emb.image_location_layer_norm.bias.detach(), self.eps, b32, None, None, mean_l, rstd_l, BV, H)
+        mean_v, rstd_v = f32(BV), f32(BV)
+        ops.ln_fwd(a32, b32, type_w[1], emb.v_LayerNorm.weight.detach(), emb.v_LayerNorm.bias.detach(), self.eps,
+                   x32, x_hi, x_lo, mean_v, rstd_v, BV, H, group=V, out_stride=S, out_off=T, p_post=p_hid,
+                   seed=seed(2))
+        sv.update(z_t=z_t, mean_t=mean_t, rstd_t=rstd_t, f_hi=f_hi, z_i=z_i, mean_i=mean_i, rstd_i=rstd_i,
+                  z_l=z_l, mean_l=mean_l, rstd_l=rstd_l, z_v=a32, mean_v=mean_v, rstd_v=rstd_v)
+
+        for l in range(self.n_layers):
+            at = self.model.bert.encoder.layer[2 * l]
+            ff = self.model.bert.encoder.layer[2 * l + 1]
+            lw = pw["layers"][l]
+            ls = dict(x_hi=x_hi)
+            # --- attention sub-layer (encoders.py:229-359 + :399-425) ---
+            qkv32 = f32(M, 3 * H)
+            ops.gemm_nt(x_hi, x_lo, lw["qkv"].hi, lw["qkv"].lo, M, 3 * H, H, 3, EPI_F32, bias=lw["qkv"].bias,
+                        out32=qkv32)
+            ctx_hi, ctx_lo, lse = b16(M, H), b16(M, H), f32(B * nh * S)
+            ops.attn_fwd(qkv32, am, ctx_hi, ctx_lo, lse, B, S, nh, 64, p_att, seed(16 * l + 3))
+            z1 = f32(M, H)
+            ops.gemm_nt(ctx_hi, ctx_lo, lw["o"].hi, lw["o"].lo, M, H, H, 3, EPI_F32, bias=lw["o"].bias, out32=z1)
+            x1_32, x1_hi, x1_lo, mean1, rstd1 = f32(M, H), b16(M, H), b16(M, H), f32(M), f32(M)
+            lno = at.attention_output.LayerNorm
+            ops.ln_fwd(z1, x32, None, lno.weight.detach(), lno.bias.detach(), self.eps, x1_32, x1_hi, x1_lo, mean1,
+                       rstd1, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
+            # --- feed-forward sub-layer (encoders.py:487-502 + :542-567) ---
+            u16, h_hi, h_lo = b16(M, I), b16(M, I), b16(M, I)
+            ops.gemm_nt(x1_hi, x1_lo, lw["w1"].hi, lw["w1"].lo, M, I, H, 3, EPI_GELU_SPLIT, bias=lw["w1"].bias,
+                        out_hi=h_hi, out_lo=h_lo, aux16=u16)
+            z2 = f32(M, H)
+            ops.gemm_nt(h_hi, h_lo, lw["w2"].hi, lw["w2"].lo, M, H, I, 3, EPI_F32, bias=lw["w2"].bias, out32=z2)
+            x2_32, x2_hi, x2_lo, mean2, rstd2 = f32(M, H), b16(M, H), b16(M, H), f32(M), f32(M)
+            lnf = ff.output.LayerNorm
+            ops.ln_fwd(z2, x1_32, None, lnf.weight.detach(), lnf.bias.detach(), self.eps, x2_32, x2_hi, x2_lo, mean2,
+                       rstd2, M, H, p_pre=p_hid, seed=seed(16 * l + 5))
+            ls.update(qkv32=qkv32, ctx_hi=ctx_hi, ctx_lo=ctx_lo, lse=lse, z1=z1, mean1=mean1, rstd1=rstd1,
+                      x1_hi=x1_hi, u16=u16, h_hi=h_hi, z2=z2, mean2=mean2, rstd2=rstd2)
+            sv["layers"].append(ls)
+            x32, x_hi, x_lo = x2_32, x2_hi, x2_lo
+        return x32.view(B, S, H), sv
+
+    # ---- backward ------------------------------------------------------------------------------------------------
+    def backward(self, sv, dx):
+        """dx: [B,S,H] fp32 gradient of the trunk output.  Returns grads in ``param_list`` order."""
+        cfg = self.model.config
+        emb = self.model.bert.embeddings
+        B, T, V, F, L, S = sv["B"], sv["T"], sv["V"], sv["F"], sv["L"], sv["S"]
+        H, I, nh = self.H, self.I, self.nh
+        M, BT, BV = B * S, B * T, B * V
+        dev = dx.device
+        p_hid, p_att, seed, pw, am = sv["p_hid"], sv["p_att"], sv["seed"], sv["pw"], sv["am"]
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
+        ws = ops.ln_bwd_ws(M, H, dev)
+        dy = dx.contiguous().view(M, H)
+        layer_grads = [None] * self.n_layers
+
+        def masked(dw, lin, rows=None):
+            m = linear_params(lin)[1]
+            if m is not None:  # SFT: grad(weight_orig) = grad(weight) (*) mask
+                ops.mask_mul(dw, m, dw)
+            return dw
+
+        for l in reversed(range(self.n_layers)):
+            at = self.model.bert.encoder.layer[2 * l]
+            ff = self.model.bert.encoder.layer[2 * l + 1]
+            lw, ls = pw["layers"][l], sv["layers"][l]
+            # feed-forward sub-layer
+            lnf = ff.output.LayerNorm
+            dz2, dt2 = f32(M, H), b16(M, H)
+            dg2, db2, dbias2 = f32(H), f32(H), f32(H)
+            ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], lnf.weight.detach(), dz2, dt2, None, dg2, db2, dbias2,
+                       ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5))
+            du16 = b16(M, I)
+            ops.gemm_nt(dt2, None, lw["w2"].t_hi, None, M, I, H, 1, EPI_DGELU_BF16, out_hi=du16, aux16=ls["u16"])
+            dx1 = f32(M, H)
+            ops.gemm_nt(du16, None, lw["w1"].t_hi, None, M, H, I, 1, EPI_F32, resid=dz2, out32=dx1)
+            dW2 = masked(dw_gemm(dt2, ls["h_hi"], M, H, I), ff.output.dense)
+            dW1 = masked(dw_gemm(du16, ls["x1_hi"], M, I, H), ff.intermediate.dense)
+            dbias1 = ops.colsum_bf16(du16, M, I, f32(I))
+            # attention sub-layer
+            lno = at.attention_output.LayerNorm
+            dz1, dt1 = f32(M, H), b16(M, H)
+            dg1, db1, dbias_o = f32(H), f32(H), f32(H)
+            ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], lno.weight.detach(), dz1, dt1, None, dg1, db1, dbias_o,
+                       ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
+            dctx = f32(M, H)
+            ops.gemm_nt(dt1, None, lw["o"].t_hi, None, M, H, H, 1, EPI_F32, out32=dctx)
+            dWo = masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), at.attention_output.dense)
+            dqkv = b16(M, 3 * H)
+            ops.attn_bwd(ls["qkv32"], am, ls["ctx_hi"], ls["ctx_lo"], dctx, ls["lse"], dqkv, B, S, nh, 64, p_att,
+                         seed(16 * l + 3))
+            dx0 = f32(M, H)
+            ops.gemm_nt(dqkv, None, lw["qkv"].t_hi, None, M, H, 3 * H, 1, EPI_F32, resid=dz1, out32=dx0)
+            dWqkv = dw_gemm(dqkv, ls["x_hi"], M, 3 * H, H)
+            sa = at.attention_self
+            for i, lin in enumerate((sa.query, sa.key, sa.value)):
+                masked(dWqkv[i * H:(i + 1) * H], lin)
+            dbqkv = ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H))
+            layer_grads[l] = [dWqkv[0:H], dbqkv[0:H], dWqkv[H:2 * H], dbqkv[H:2 * H], dWqkv[2 * H:], dbqkv[2 * H:],
+                              dWo, dbias_o, dg1, db1, dW1, dbias1, dW2, dbias2, dg2, db2]
+            dy = dx0
+            sv["layers"][l] = None  # release this layer's activations
+
+        # --- embeddings backward (dy = dL/dX0 [M,H]) ---
+        type_w = emb.new_token_type_embeddings.weight
+        dword = torch.zeros_like(emb.word_embeddings.weight)
+        dpos = torch.zeros_like(emb.position_embeddings.weight)
+        dtype_ = torch.zeros_like(type_w)
+        # box rows
+        dz_v, dg_v, db_v, dtype1 = f32(BV, H), f32(H), f32(H), f32(H)
+        ops.ln_bwd(dy, sv["z_v"], sv["mean_v"], sv["rstd_v"], emb.v_LayerNorm.weight.detach(), dz_v, None, None,
+                   dg_v, db_v, dtype1, ws, BV, H, group=V, out_stride=S, out_off=T, p_post=p_hid, seed=seed(2))
+        dimg16, dg_i, db_i, dbias_img = b16(BV, H), f32(H), f32(H), f32(H)
+        ops.ln_bwd(dz_v, sv["z_i"], sv["mean_i"], sv["rstd_i"], emb.image_layer_norm.weight.detach(), None, dimg16,
+                   None, dg_i, db_i, dbias_img, ws, BV, H)
+        dWimg = masked(dw_gemm(dimg16, sv["f_hi"], BV, H, F), emb.image_embeddings)
+        dloc32, dg_l, db_l = f32(BV, H), f32(H), f32(H)
+        ops.ln_bwd(dz_v, sv["z_l"], sv["mean_l"], sv["rstd_l"], emb.image_location_layer_norm.weight.detach(), None,
+                   None, dloc32, dg_l, db_l, None, ws, BV, H)
+        dWl = torch.zeros_like(emb.image_location_embeddings.weight)
+        dbl = torch.zeros_like(emb.image_location_embeddings.bias)
+        ops.loc_linear_bwd(sv["locs"], dloc32, dWl, dbl, BV, L, H)
+        # text rows
+        dz_t, dg_e, db_e = f32(BT, H), f32(H), f32(H)
+        ops.ln_bwd(dy, sv["z_t"], sv["mean_t"], sv["rstd_t"], emb.LayerNorm.weight.detach(), dz_t, None, None, dg_e,
+                   db_e, None, ws, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
+        ops.embed_text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id))
+        dtype_[1] += dtype1  # image_token_type_embeddings is new_token_type_embeddings (embeddings.py:628)
+        grads = [dword, dpos, dtype_, dg_e, db_e, dWimg, dbias_img, dWl, dbl, dg_i, db_i, dg_l, db_l, dg_v, db_v]
+        for lg in layer_grads:
+            grads += lg
+        return grads
+
+
+class UC2TrunkFunction(torch.autograd.Function):
+    """autograd boundary of the native trunk: (batch, *params) -> X_final [B,S,H]."""
+
+    @staticmethod
+    def forward(ctx, engine, training, ids, feats, locs, seg, tmask, imask, *params):
+        out, sv = engine.forward(ids, feats, locs, seg, tmask, imask, training)
+        ctx.engine = engine
+        ctx.sv = sv
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        grads = ctx.engine.backward(ctx.sv, dx)
+        ctx.sv = None
+        needs = ctx.needs_input_grad[8:]
+        grads = [g if need else None for g, need in zip(grads, needs)]
+        return (None,) * 8 + tuple(grads)

@@ -1,0 +1,150 @@
+"""Thin tensor-level wrappers over the C ABI (include/vlhip.h).  Tensors are torch CUDA(=HIP) tensors used
+purely as device-memory handles; every op enqueues on torch's current stream.  CPU tensors are rejected."""
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+EPI_F32, EPI_GELU_SPLIT, EPI_DGELU_BF16, EPI_BF16, EPI_SPLIT = 0, 1, 2, 3, 4
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("clg_vqa_amd: native ops need device (cuda/HIP) tensors; got a CPU tensor -- the product "
+                           "path has no CPU fallback")
+    if not t.is_contiguous():
+        raise RuntimeError("clg_vqa_amd: native ops need contiguous tensors")
+    return t.data_ptr()
+
+
+def _pld(t):
+    """pointer + leading dimension of a 2-D row-major tensor whose rows may be strided (a column slice)."""
+    if t is None:
+        return None, 0
+    if not t.is_cuda:
+        raise RuntimeError("clg_vqa_amd: native ops need device tensors (no CPU fallback)")
+    assert t.dim() == 2 and t.stride(1) == 1, "need a row-major 2-D tensor"
+    return t.data_ptr(), t.stride(0)
+
+
+def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=None, out32=None, out_hi=None,
+            out_lo=None, aux16=None):
+    """C[M,N] = A[M,K] . B[N,K]^T (+epilogue); operands are bf16 2-D tensors (row-major, ld = stride(0))."""
+    pa, lda = _pld(a_hi)
+    pb, ldb = _pld(b_hi)
+    pal = _pld(a_lo)[0] if a_lo is not None else None
+    pbl = _pld(b_lo)[0] if b_lo is not None else None
+    po32, ldc = _pld(out32)
+    ph, ld16 = _pld(out_hi)
+    pl = _pld(out_lo)[0] if out_lo is not None else None
+    px = _pld(aux16)[0] if aux16 is not None else None
+    if resid is not None:
+        assert resid.stride(0) == ldc
+    _lib.check(_lib.lib().vl_gemm_nt(pa, pal, lda, pb, pbl, ldb, M, N, K, passes, epilogue, _p(bias),
+                                     _pld(resid)[0] if resid is not None else None, po32, ldc, ph, pl, px, ld16,
+                                     _stream()), "vl_gemm_nt")
+
+
+def attn_fwd(qkv32, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed):
+    _lib.check(_lib.lib().vl_attn_fwd(_p(qkv32), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
+                                      float(p_drop), int(seed), _stream()), "vl_attn_fwd")
+
+
+def attn_bwd(qkv32, addmask, ctx_hi, ctx_lo, dctx32, lse, dqkv16, B, S, nh, dh, p_drop, seed):
+    _lib.check(_lib.lib().vl_attn_bwd(_p(qkv32), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(dctx32), _p(lse),
+                                      _p(dqkv16), B, S, nh, dh, float(p_drop), int(seed), _stream()), "vl_attn_bwd")
+
+
+def ln_fwd(y, resid, addvec, gamma, beta, eps, out32, out_hi, out_lo, mean, rstd, M, H, group=None, out_stride=0,
+           out_off=0, p_pre=0.0, p_post=0.0, seed=0):
+    group = M if group is None else group
+    _lib.check(_lib.lib().vl_ln_fwd(_p(y), _p(resid), _p(addvec), _p(gamma), _p(beta), float(eps), _p(out32),
+                                    _p(out_hi), _p(out_lo), _p(mean), _p(rstd), M, H, group, out_stride, out_off,
+                                    float(p_pre), float(p_post), int(seed), _stream()), "vl_ln_fwd")
+
+
+def ln_bwd_ws(M, H, device):
+    return torch.empty(_lib.lib().vl_ln_bwd_ws_floats(M, H), dtype=torch.float32, device=device)
+
+
+def ln_bwd(dy, z, mean, rstd, gamma, dz, dpre16, dpre32, dgamma, dbeta, dbias, ws, M, H, group=None, out_stride=0,
+           out_off=0, p_pre=0.0, p_post=0.0, seed=0):
+    group = M if group is None else group
+    _lib.check(_lib.lib().vl_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dpre16), _p(dpre32),
+                                    _p(dgamma), _p(dbeta), _p(dbias), _p(ws), M, H, group, out_stride, out_off,
+                                    float(p_pre), float(p_post), int(seed), _stream()), "vl_ln_bwd")
+
+
+def mask_mul(a, m, out):
+    """out = a (*) m : SFT weight_orig * weight_mask and grad (*) mask."""
+    assert a.numel() == m.numel() == out.numel()
+    _lib.check(_lib.lib().vl_mask_mul(_p(a), _p(m), _p(out), a.numel(), _stream()), "vl_mask_mul")
+    return out
+
+
+def weight_prep(w32, mask32, w_hi, w_lo, wt_hi):
+    """W[N,K] (*mask) -> w_hi/w_lo (row slices of a packed [*,K] buffer) and wt_hi (column slice of [K,*])."""
+    N, K = w32.shape
+    ph, ldw = _pld(w_hi) if w_hi is not None else (None, K)
+    pl = _pld(w_lo)[0] if w_lo is not None else None
+    pt, ldt = _pld(wt_hi) if wt_hi is not None else (None, N)
+    _lib.check(_lib.lib().vl_weight_prep(_p(w32), _p(mask32), ph, pl, pt, N, K, ldw, ldt, _stream()),
+               "vl_weight_prep")
+
+
+def split_f32(x32, hi, lo=None):
+    _lib.check(_lib.lib().vl_split_f32(_p(x32), _p(hi), _p(lo), x32.numel(), _stream()), "vl_split_f32")
+
+
+def transpose_bf16(src, dst, M, N):
+    ps, ld_in = _pld(src)
+    pd, ld_out = _pld(dst)
+    _lib.check(_lib.lib().vl_transpose_bf16(ps, pd, M, N, ld_in, ld_out, _stream()), "vl_transpose_bf16")
+
+
+def colsum_bf16(x16, M, N, out32):
+    ws = torch.empty(_lib.lib().vl_colsum_ws_floats(M, N), dtype=torch.float32, device=x16.device)
+    px, ld = _pld(x16)
+    _lib.check(_lib.lib().vl_colsum_bf16(px, M, N, ld, _p(ws), _p(out32), _stream()), "vl_colsum_bf16")
+    return out32
+
+
+def addmask(text_mask, img_mask, out, B, T, V):
+    _lib.check(_lib.lib().vl_addmask(_p(text_mask), _p(img_mask), _p(out), B, T, V, _stream()), "vl_addmask")
+
+
+def embed_text_fwd(ids, seg, word, pos, typ, z32, B, T, H, pad_id):
+    _lib.check(_lib.lib().vl_embed_text_fwd(_p(ids), _p(seg), _p(word), _p(pos), _p(typ), _p(z32), B, T, H, pad_id,
+                                            _stream()), "vl_embed_text_fwd")
+
+
+def embed_text_bwd(ids, seg, dz32, dword, dpos, dtyp, B, T, H, pad_id):
+    _lib.check(_lib.lib().vl_embed_text_bwd(_p(ids), _p(seg), _p(dz32), _p(dword), _p(dpos), _p(dtyp), B, T, H,
+                                            pad_id, _stream()), "vl_embed_text_bwd")
+
+
+def loc_linear_fwd(loc, w, b, y32, R, L, H):
+    _lib.check(_lib.lib().vl_loc_linear_fwd(_p(loc), _p(w), _p(b), _p(y32), R, L, H, _stream()), "vl_loc_linear_fwd")
+
+
+def loc_linear_bwd(loc, dy32, dw, db, R, L, H):
+    _lib.check(_lib.lib().vl_loc_linear_bwd(_p(loc), _p(dy32), _p(dw), _p(db), R, L, H, _stream()),
+               "vl_loc_linear_bwd")
+
+
+def adamw(param, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, seg_wd, beta1, beta2, eps, step, correct_bias, lr_mult,
+          grad_scale_dev=None, grad_scale=1.0, zero_grad=False):
+    _lib.check(_lib.lib().vl_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(seg_end),
+                                   _p(seg_lr), _p(seg_wd), seg_end.numel(), float(beta1), float(beta2), float(eps),
+                                   int(step), int(bool(correct_bias)), float(lr_mult), _p(grad_scale_dev),
+                                   float(grad_scale), int(bool(zero_grad)), _stream()), "vl_adamw")
+
+
+def sumsq(x, out):
+    _lib.check(_lib.lib().vl_sumsq(_p(x), x.numel(), _p(out), _stream()), "vl_sumsq")

@@ -1,0 +1,78 @@
+"""Loss / score glue of the VQA (GQA) fine-tuning step -- the `VL-classifier-GQA` branches of
+volta/volta/task_utils.py (``ForwardModelsTrain`` :308-428, ``ForwardModelsVal`` :195-269,
+``compute_score_with_logits`` :706-711, ``LoadLoss`` / ``LossMap`` :179-189).
+
+The loss operates on the [B, 1842] logits only (negligible work) and is written with torch
+tensor ops on the device; everything upstream of the logits is the native engine.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+LossMap = {
+    "BCEWithLogitLoss": nn.BCEWithLogitsLoss(reduction="mean"),
+    "CrossEntropyLoss": nn.CrossEntropyLoss(),
+}
+
+
+def LoadLoss(args, task_cfg, task_id):
+    task = "TASK" + task_id
+    loss_name = getattr(args, "loss", None) or task_cfg[task]["loss"]
+    return LossMap[loss_name]
+
+
+def compute_score_with_logits(logits, labels):
+    idx = torch.max(logits, 1)[1]
+    one_hots = torch.zeros_like(labels)
+    one_hots.scatter_(1, idx.view(-1, 1), 1)
+    return one_hots * labels
+
+
+def _to_device(batch, device):
+    return tuple(t.to(device=device, non_blocking=True) for t in batch)
+
+
+def ForwardModelsTrain(config, task_cfg, device, task_id, batch, model, criterion):
+    """Returns (loss, batch_score) like the reference (task_utils.py:308-428, GQA branch :413-428):
+    loss = CE(logits, argmax target) * C + semantic_lambda * mean_b(sum_top10 p * dist) * C."""
+    batch = _to_device(batch, device)
+    features, spatials, image_mask, question, target, input_mask, segment_ids, question_id, ixs, distances = batch
+    batch_size = features.size(0)
+    ttype = task_cfg[task_id]["type"]
+    vil_prediction = model(question, features, spatials, task_id, segment_ids, input_mask, image_mask)[0]
+    if ttype == "VL-classifier-GQA":
+        semantic_lambda = task_cfg[task_id]["semantic_lambda"]
+        p_top_k, idx_top_k = torch.topk(F.softmax(vil_prediction, dim=-1), k=10)
+        semantic_loss = p_top_k * distances[torch.arange(distances.size(0), device=distances.device).unsqueeze(1),
+                                            idx_top_k]
+        semantic_loss = torch.mean(torch.sum(semantic_loss, dim=-1), dim=0)
+        loss = criterion(vil_prediction, torch.argmax(target.long(), dim=1))
+        loss = loss.mean() * target.size(1)
+        loss = loss + (semantic_lambda * semantic_loss.mean()) * target.size(1)
+        batch_score = compute_score_with_logits(vil_prediction, target).sum() / float(batch_size)
+    elif ttype == "VL-classifier":
+        loss = criterion(vil_prediction, target)
+        loss = loss.mean() * target.size(1)
+        batch_score = compute_score_with_logits(vil_prediction, target).sum() / float(batch_size)
+    else:
+        raise ValueError("clg_vqa_amd.task_utils: unsupported task type %s" % ttype)
+    return loss, batch_score
+
+
+def ForwardModelsVal(config, task_cfg, device, task_id, batch, model, criterion):
+    """Returns (float loss, float batch_score, batch_size) (task_utils.py:195-269): CE * C, summed score."""
+    batch = _to_device(batch, device)
+    features, spatials, image_mask, question, target, input_mask, segment_ids = batch[:7]
+    batch_size = features.size(0)
+    with torch.no_grad():
+        vil_prediction = model(question, features, spatials, task_id, segment_ids, input_mask, image_mask)[0]
+    ttype = task_cfg[task_id]["type"]
+    if ttype == "VL-classifier-GQA":
+        loss = criterion(vil_prediction, torch.argmax(target.long(), dim=1))
+    elif ttype == "VL-classifier":
+        loss = criterion(vil_prediction, target)
+    else:
+        raise ValueError("clg_vqa_amd.task_utils: unsupported task type %s" % ttype)
+    loss = loss.mean() * target.size(1)
+    batch_score = compute_score_with_logits(vil_prediction, target).sum()
+    return float(loss), float(batch_score), batch_size

@@ -1,0 +1,153 @@
+/* vlhip.h -- C ABI of libvlhip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the UC2 / M3P VQA
+ * fine-tuning hot path of nooralahzadeh/CLG-VQA.
+ *
+ * This boundary replaces the reference's only native plugin boundary on this path -- the pybind11 torch
+ * extensions of vendored apex (volta/apex/csrc/layer_norm_cuda.cpp:121-239 forward_affine/backward_affine,
+ * volta/apex/csrc/flatten_unflatten.cpp:1-18, volta/apex/csrc/multi_tensor_scale_kernel.cu) -- and the eager
+ * torch ops the reference issues around it (file:line cited per entry point below; paths are relative to
+ * /root/reference/volta).
+ *
+ * Conventions
+ *   - Plain pointers and sizes only; no torch / HIP types in signatures (`stream` is a hipStream_t passed as
+ *     void*; NULL = the default stream).  All pointers are DEVICE pointers unless stated otherwise.
+ *   - The caller owns every buffer (incl. workspaces); the library never allocates, frees or retains them.
+ *   - Every call only enqueues work on `stream` and returns immediately (asynchronous, re-entrant).
+ *   - Return value: 0 on success, negative on error (-1 bad argument / unsupported shape, -3 HIP launch
+ *     error).  The message is available from vl_last_error() (thread-local).  Nothing throws or aborts.
+ *   - "bf16" buffers hold raw bfloat16 bits (uint16).  A "(hi, lo) split" of an fp32 tensor x is the pair
+ *     hi = bf16(x), lo = bf16(x - hi): x ~= hi + lo to 16 significant bits (Precision).
+ *   - Row-major everywhere; `ld*` are leading dimensions in ELEMENTS.
+ */
+#ifndef VLHIP_H_
+#define VLHIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int vl_version(void);
+const char* vl_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GEMM  C[M,N] = A[M,K] * B[N,K]^T  (+ epilogue), bf16 MFMA with fp32 accumulation.
+ * Replaces: nn.Linear forward GEMMs encoders.py:229-246 (Q,K,V), :411-414 (attention out-proj), :496-501
+ * (FFN1 + erf-GELU :131-137), :553-556 (FFN2), embeddings.py:660 (region projection), encoders.py:603-607
+ * (pooler), :788-815 (classifier) and the autograd dX / dW products of the same layers.
+ * passes = 1: bf16 operands (a_lo / b_lo ignored).  passes = 3: 3-term split product (fp32-grade).
+ * K, lda, ldb multiples of 8; operand pointers 16-byte aligned; M, N arbitrary.
+ * ------------------------------------------------------------------------------------------------------------ */
+enum {
+  VL_EPI_F32 = 0,        /* out32[m,n]  = acc + bias[n] (bias may be NULL) + resid32[m,n] (may be NULL)           */
+  VL_EPI_GELU_SPLIT = 1, /* u = acc+bias; aux16 = bf16(u); (out_hi,out_lo) = split(gelu_erf(u))                   */
+  VL_EPI_DGELU_BF16 = 2, /* out_hi = bf16(acc * gelu_erf'(aux16[m,n]))   (backward through FFN1's activation)      */
+  VL_EPI_BF16 = 3,       /* out_hi = bf16(acc + bias)                                                             */
+  VL_EPI_SPLIT = 4       /* (out_hi,out_lo) = split(acc + bias)                                                   */
+};
+int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
+               int64_t M, int64_t N, int64_t K, int passes, int epilogue, const float* bias, const float* resid32,
+               float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused V&L attention core over the single stream X = [text ; boxes]  (S = T + V <= 160, head dim 64).
+ * Replaces encoders.py:255-341: four gated score blocks, two concatenated softmaxes, four dropouts, four P.V
+ * products == one multi-head attention with the additive key mask [t_mask ; v_mask] (encoders.py:978-995).
+ * qkv32   [B*S, 3*nh*64] fp32, columns [Q | K | V], head h at h*64 inside each third.
+ * addmask [B*S] fp32 additive key mask (0 or -10000).
+ * ctx     (hi, lo) split [B*S, nh*64] -- attention output in [b, s, h*64+d] order (permute fused).
+ * lse     [B*nh*S] fp32 row log-sum-exp of the masked, scaled scores (saved for backward).
+ * Dropout on the probabilities (p_drop, seed): keep-mask regenerated in backward from the same (seed).
+ * exact fp32 arithmetic (v_mfma_f32_16x16x4_f32).
+ * ------------------------------------------------------------------------------------------------------------ */
+int vl_attn_fwd(const float* qkv32, const float* addmask, void* ctx_hi, void* ctx_lo, float* lse, int64_t B,
+                int64_t S, int64_t nh, int64_t dh, float p_drop, uint64_t seed, void* stream);
+/* dctx32 [B*S, nh*64] fp32 -> dqkv16 [B*S, 3*nh*64] bf16 (same column layout as qkv32). */
+int vl_attn_bwd(const float* qkv32, const float* addmask, const void* ctx_hi, const void* ctx_lo,
+                const float* dctx32, const float* lse, void* dqkv16, int64_t B, int64_t S, int64_t nh, int64_t dh,
+                float p_drop, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * (dropout +) residual + LayerNorm, forward and backward.
+ * Replaces apex fused_layer_norm_cuda.forward_affine / backward_affine (apex/csrc/layer_norm_cuda.cpp:139-239,
+ * kernels layer_norm_cuda_kernel.cu:279-322, :403-637) == BertLayerNorm (encoders.py:44-62), fused with the
+ * surrounding eager ops of BertGatedSelfOutput / BertGatedOutput (encoders.py:411-425, :553-567) and of
+ * UC2Embeddings (embeddings.py:653-666):
+ *     z   = dropout_pre(y) + resid + addvec            (resid, addvec may be NULL; z is written back over y)
+ *     out = dropout_post(gamma * (z - mean) * rsqrt(var + eps) + beta)        biased var, eps inside sqrt
+ * Output row r of the M input rows goes to row (r / group)*out_stride + out_off + (r % group) of out32/out_hi/
+ * out_lo (group == M, out_stride == 0, out_off == 0 for the identity map) -- this is how the text rows and box
+ * rows are interleaved into the single [B, S, H] stream.  H must be a multiple of 256, H <= 2048.
+ * mean, rstd: [M] fp32 saved for backward.  out_hi/out_lo may be NULL.
+ * ------------------------------------------------------------------------------------------------------------ */
+int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, const float* gamma, const float* beta,
+              float eps, float* out32, void* out_hi, void* out_lo, float* mean, float* rstd, int64_t M, int64_t H,
+              int64_t group, int64_t out_stride, int64_t out_off, float p_pre, float p_post, uint64_t seed,
+              void* stream);
+/* Backward: dy32 is read through the same row map; dz32 [M,H] = dL/dz (what flows to the residual branch);
+ * dpre16 (bf16, may be NULL) / dpre32 (fp32, may be NULL) = dL/dy = dz * keep_pre  (what flows into the producing
+ * GEMM); column sums over the M rows: dgamma, dbeta, dbias (= colsum(dL/dy), the producing dense layer's bias
+ * gradient; may be NULL).  partial_ws: >= vl_ln_bwd_ws_floats(M, H) floats of scratch. */
+int64_t vl_ln_bwd_ws_floats(int64_t M, int64_t H);
+int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd, const float* gamma,
+              float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta, float* dbias,
+              float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
+              float p_pre, float p_post, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sparse fine-tuning mask kernels.
+ * vl_mask_mul: out = a (*) m -- torch.nn.utils.prune forward pre-hook weight = weight_orig * weight_mask and its
+ * autograd grad(weight_orig) = grad(weight) * mask (train_task_sft.py:128-132; torch prune.py:20-31).
+ * vl_weight_prep: one pass per optimizer step over a Linear weight W[N,K] (optionally (*) mask): writes the
+ * (hi, lo) split for forward GEMMs and the transposed hi copy Wt[K,N] for the dX GEMM.  Any of the outputs may
+ * be NULL.
+ * ------------------------------------------------------------------------------------------------------------ */
+int vl_mask_mul(const float* a, const float* m, float* out, int64_t n, void* stream);
+int vl_weight_prep(const float* w32, const float* mask32, void* w_hi, void* w_lo, void* wt_hi, int64_t N,
+                   int64_t K, int64_t ldw, int64_t ldt, void* stream);
+
+/* Elementwise / layout helpers. */
+int vl_split_f32(const float* x32, void* hi, void* lo, int64_t n, void* stream); /* lo may be NULL (plain cast) */
+int vl_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t ld_out, void* stream);
+/* out32[n] = sum_m x16[m,n]; ws >= vl_colsum_ws_floats(M,N) floats. */
+int64_t vl_colsum_ws_floats(int64_t M, int64_t N);
+int vl_colsum_bf16(const void* x16, int64_t M, int64_t N, int64_t ld, float* ws, float* out32, void* stream);
+int vl_addmask(const int64_t* text_mask, const int64_t* img_mask, float* addmask, int64_t B, int64_t T, int64_t V,
+               void* stream); /* (1 - m) * -10000 over [text ; boxes], encoders.py:978-995 */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * UC2Embeddings pieces (embeddings.py:636-669).
+ * text: z[b*T+t,:] = word[ids] + pos[cumsum(ids!=pad)*(ids!=pad)+pad] + type[seg]   (RoBERTa position ids,
+ *       embeddings.py:157-170); backward scatter-adds dz into the dense tables with float atomics.
+ * loc : y[r,:] = loc[r,0:L] . Wl[:,0:L]^T + bl  (L = num_locs <= 8) and its backward.
+ * ------------------------------------------------------------------------------------------------------------ */
+int vl_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
+                      const float* type, float* z32, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream);
+int vl_embed_text_bwd(const int64_t* ids, const int64_t* seg, const float* dz32, float* dword, float* dpos,
+                      float* dtype, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream);
+int vl_loc_linear_fwd(const float* loc, const float* w, const float* b, float* y32, int64_t R, int64_t L, int64_t H,
+                      void* stream);
+/* dw [H,L], db [H] are ACCUMULATED with atomics: zero them first. */
+int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db, int64_t R, int64_t L, int64_t H,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused optimizer step over a flat parameter arena (next-row f1 of SURVEY.md section 8):
+ * AdamW as pytorch_transformers.optimization.AdamW (call site train_task.py:264-268): bias-corrected step size,
+ * decoupled weight decay applied after the Adam update; grads pre-scaled by *grad_scale_dev (device scalar, e.g. the
+ * clip coefficient of train_task.py:330) when non-NULL, else by `grad_scale`.  seg_end[i] = exclusive end offset of
+ * segment i in the arena, seg_lr / seg_wd its base lr and weight decay (215 one-tensor param groups,
+ * train_task.py:249-260); `lr_mult` = the LR schedule's multiplier for this step (WarmupLinearSchedule,
+ * train_task.py:274).  `step` = 1-based optimizer step.  Also zeroes the gradient when zero_grad != 0.
+ * ------------------------------------------------------------------------------------------------------------ */
+int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const int64_t* seg_end,
+             const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1, float beta2, float eps,
+             int64_t step, int correct_bias, float lr_mult, const float* grad_scale_dev, float grad_scale,
+             int zero_grad, void* stream);
+/* out[0] += sum(x^2) over n floats (atomic; zero out[0] first). */
+int vl_sumsq(const float* x, int64_t n, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VLHIP_H_ */

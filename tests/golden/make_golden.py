@@ -134,6 +134,7 @@ def run_model_case(BertConfig, BertForVLTasks, task_utils, cfg, seed, out_path, 
         names.append(n)
         out["grad::" + n] = grad_digest(p.grad)
     out["grad_names"] = np.frombuffer("\n".join(names).encode(), dtype=np.uint8)
+    out["state_keys"] = np.frombuffer("\n".join(model.state_dict().keys()).encode(), dtype=np.uint8)
     np.savez_compressed(out_path, **out)
     print("wrote", out_path, "loss=%.6f score=%.4f n_grads=%d size=%.1f KB" % (
         float(loss), float(score), len(names), os.path.getsize(out_path) / 1024))

@@ -1,0 +1,68 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol of include/vlhip.h; host logic (config,
+state_dict surface, loader) behaves like the reference's."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+from helpers import TASK_CFG, golden_config, load_golden, uc2_cfg_dict
+from clg_vqa_amd import _lib
+from clg_vqa_amd.config import BertConfig, M3PConfig, uc2_topology_check
+from clg_vqa_amd.encoders import BertForVLTasks
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "build it first: python -c 'import __graft_entry__ as g; g.build()'"
+    names = _lib.header_symbols()
+    assert len(names) >= 20
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), n
+    assert set(names) == set(_lib._SIGS), "python binding table out of sync with include/vlhip.h"
+    assert _lib.lib().vl_version() == 100
+
+
+def test_state_dict_surface_matches_reference_fixture():
+    for name in ("uc2_tiny.npz", "uc2_wide.npz"):
+        g = load_golden(name)
+        cfg = golden_config(g)
+        if cfg.hidden_size // cfg.num_attention_heads != 64:
+            with pytest.raises(ValueError, match="head dim 64"):
+                BertForVLTasks(cfg, TASK_CFG, ["TASK15"])
+            continue
+        m = BertForVLTasks(cfg, TASK_CFG, ["TASK15"])
+        assert list(m.state_dict().keys()) == bytes(g["state_keys"]).decode().split("\n")
+
+
+def test_full_config_census_on_meta_device():
+    with torch.device("meta"):
+        m = BertForVLTasks(BertConfig.from_dict(uc2_cfg_dict()), TASK_CFG, ["TASK15"])
+    assert len(m.state_dict()) == 408
+    assert sum(p.numel() for p in m.parameters()) == 281637426
+    assert len(m.engine.param_list()) == 15 + 12 * 16
+
+
+def test_config_defaults_and_topology_guard():
+    c = BertConfig.from_dict({"hidden_size": 768})
+    assert c.fusion_act == "relu" and c.layer_norm_eps == 1e-12 and c.fusion_method == "mul"
+    assert M3PConfig.from_dict({}).n_layers == 12
+    bad = uc2_cfg_dict(n_layers=2)
+    bad["single_ln_sublayers"] = [0, 1]
+    with pytest.raises(ValueError, match="UC2 single-stream topology"):
+        uc2_topology_check(BertConfig.from_dict(bad))
+
+
+def test_from_pretrained_local_file(tmp_path):
+    cfg = BertConfig.from_dict(uc2_cfg_dict(n_layers=1, vocab=64))
+    m = BertForVLTasks(cfg, TASK_CFG, ["TASK15"])
+    sd = {k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")
+          .replace("bert.", "roberta.", 1): v for k, v in m.state_dict().items()}
+    path = tmp_path / "pytorch_model.bin"
+    torch.save(sd, str(path))
+    m2 = BertForVLTasks.from_pretrained(str(tmp_path), config=cfg, task_cfg=TASK_CFG, task_ids=["TASK15"])
+    assert not m2.training
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    assert BertForVLTasks.from_pretrained(str(tmp_path / "nope.bin"), config=cfg, task_cfg=TASK_CFG,
+                                          task_ids=["TASK15"]) is None
