@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- VQA train samples/sec (UC2, 36 boxes, seq 56, bs 256 per GPU) on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step of BASELINE.json configs[1] on one synthetic batch already resident in HBM:
+forward (dropout on) + GQA loss with semantic prior + backward + gradient all-reduce (N > 1) + clip + AdamW +
+zero-grad.  Weak scaling: 256 samples per GPU.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      the dominant kernel (the 3-pass bf16 MFMA GEMM of the forward): algorithmic FLOP (2*M*N*K per launch,
+                NOT x3 for the split passes) / HIP-event-measured duration over the timed region, against the dense
+                bf16 MFMA peak (2.5 PFLOP/s); "mfma_issue_frac" = passes x that (what the matrix pipe really issues).
+  cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on the box's host cores on a
+                bounded sample: UC2 full config, micro-batch 32, fwd+bwd, N = 1 / rank 0 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def uc2_full_cfg():
+    from helpers import uc2_cfg_dict
+    return uc2_cfg_dict()  # volta/config/uc2_base.json values: 12 layers, H 768, 12 heads, I 3072, vocab 250002
+
+
+class GemmTimer(object):
+    """HIP-event pairs around launches of the dominant kernel, on the stream they are launched on."""
+
+    def __init__(self):
+        self.records = []  # (passes, flops, ev0, ev1)
+        self.enabled = False
+
+    def wrap(self, ops_mod):
+        inner = ops_mod.gemm_nt
+        timer = self
+
+        def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw):
+            if not timer.enabled:
+                return inner(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            inner(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw)
+            e1.record()
+            timer.records.append((passes, 2.0 * M * N * K, e0, e1))
+
+        ops_mod.gemm_nt = gemm_nt
+
+    def summary(self):
+        out = {}
+        for passes in (1, 3):
+            recs = [r for r in self.records if r[0] == passes]
+            if recs:
+                ms = sum(r[2].elapsed_time(r[3]) for r in recs)
+                out[passes] = dict(launches=len(recs), flops=sum(r[1] for r in recs), ms=ms)
+        return out
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle fwd+bwd on the host cores: UC2 full config, micro-batch 32."""
+    from helpers import TASK_CFG
+    from oracle import uc2_oracle as O
+    from clg_vqa_amd.config import BertConfig
+    from clg_vqa_amd.synthetic import make_batch
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    config = BertConfig.from_dict(uc2_full_cfg())
+    torch.manual_seed(0)
+    model = O.OracleUC2ForVLTasks(config, TASK_CFG, ["TASK15"])
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Linear, torch.nn.Embedding)):
+            m.weight.data.normal_(0.0, 0.02)
+    model.train()
+    mb = 32
+    batch = make_batch(mb, seed=99)
+    times = []
+    t_start = time.time()
+    for i in range(6):
+        t0 = time.time()
+        model.zero_grad()
+        loss, _, _ = O.forward_train(model, batch)
+        loss.backward()
+        dt = time.time() - t0
+        if i > 0:
+            times.append(dt)
+        if time.time() - t_start > seconds_budget and len(times) >= 2:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return dict(value=mb / med, unit="samples/s", cores=cores, kind="port",
+                sample="oracle (CPU restatement of volta BertForVLTasks, fp32 eager torch) UC2 full config, "
+                       "micro-batch 32, T=20 V=36, fwd+bwd with dropout, median of %d steps after 1 warm-up"
+                       % len(times))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sft", action="store_true", help="configs[2]: train under a Bernoulli(0.59) SFT mask")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from helpers import TASK_CFG
+    from clg_vqa_amd import ops, task_utils
+    from clg_vqa_amd.config import BertConfig
+    from clg_vqa_amd.encoders import BertForVLTasks
+    from clg_vqa_amd.optim import FusedAdamW
+    from clg_vqa_amd.synthetic import make_batch
+
+    timer = GemmTimer()
+    timer.wrap(ops)
+
+    config = BertConfig.from_dict(uc2_full_cfg())
+    torch.manual_seed(1234)  # identical replicas on every rank (apex DDP broadcasts from rank 0 instead)
+    model = BertForVLTasks(config, TASK_CFG, ["TASK15"]).to(dev)
+    if args.sft:
+        from torch.nn.utils import prune
+        sys.path.insert(0, ROOT)
+        from oracle.uc2_oracle import uc2_prunable_names
+        gen = torch.Generator(device="cpu").manual_seed(4321)
+        mods = dict(model.named_modules())
+        for n in uc2_prunable_names():
+            w = mods[n].weight
+            mask = (torch.rand(w.shape, generator=gen) < 0.59).float().to(dev)
+            w.data.mul_(mask)
+            prune.CustomFromMask.apply(mods[n], "weight", mask=mask)
+    model.train()
+    # reference hyper-parameters: experiments/zero_shot/uc2/xgqa/train.dtu.sh:20-28
+    opt = FusedAdamW(model, base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True,
+                     max_grad_norm=1.0, warmup_steps=100, t_total=100000)
+    batch = tuple(t.to(dev) for t in make_batch(args.batch, seed=1234 + rank))
+    crit = torch.nn.CrossEntropyLoss()
+
+    def step():
+        loss, score = task_utils.ForwardModelsTrain(config, TASK_CFG, dev, "TASK15", batch, model, crit)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss)
+
+    if rank == 0:
+        value = world * args.batch * args.steps / elapsed
+        gs = timer.summary()
+        roof = None
+        if 3 in gs:
+            ach = gs[3]["flops"] / (gs[3]["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel="gemm_nt_kernel<3,*> (forward, 3-pass split bf16)", achieved=round(ach, 2),
+                        peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        traffic=None, mfma_passes=3, mfma_issue_frac=round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        launches=gs[3]["launches"], avg_launch_us=round(1e3 * gs[3]["ms"] / gs[3]["launches"], 2))
+            if 1 in gs:
+                a1 = gs[1]["flops"] / (gs[1]["ms"] * 1e-3) / 1e12
+                roof["backward_gemm"] = dict(kernel="gemm_nt_kernel<1,*> (backward, bf16)", achieved=round(a1, 2),
+                                             frac=round(a1 / MFMA_BF16_PEAK_TFLOPS, 4), launches=gs[1]["launches"],
+                                             avg_launch_us=round(1e3 * gs[1]["ms"] / gs[1]["launches"], 2))
+        line = {
+            "metric": "VQA train samples/sec (UC2, 36 boxes, seq56, bs256)",
+            "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "UC2 full config (12 layers, H768, 12 heads, I3072, vocab 250002), GQA 1842 labels, "
+                                   "T=20 + V=36 (S=56), bs %d per GPU, %s fine-tune with_prior, dropout 0.1, "
+                                   "full step = fwd+loss+bwd+allreduce+clip+AdamW+zero_grad" % (
+                                       args.batch, "SFT-masked" if args.sft else "dense"),
+                       "global_batch": world * args.batch, "seq_len": 56, "parallelism": "dp%d" % world,
+                       "precision": "forward GEMMs 3-pass split bf16 MFMA (fp32-grade, logits within 1e-3); attention "
+                                    "core fp32 MFMA; backward GEMMs bf16 MFMA; fp32 residual stream / LN / optimizer",
+                       "algorithmic_tflop_per_step": round(29.241e-3 * world * args.batch, 3), "final_loss": final_loss},
+            "roofline": roof,
+        }
+        line["step_tflops"] = round(29.241e-3 * world * args.batch / (elapsed / args.steps), 2)
+        if world == 1 and not args.no_cpu_baseline:
+            del model, opt
+            torch.cuda.empty_cache()
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

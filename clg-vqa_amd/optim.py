@@ -1,0 +1,159 @@
+"""Fused optimizer step + gradient reducer over flat HBM arenas.
+
+Reference semantics restated:
+* parameter grouping -- one group per tensor, ``lr = 1e-4 if "vil_" in name else base_lr``, weight decay 0 for names
+  containing "bias" / "LayerNorm.bias" / "LayerNorm.weight" (volta/train_task.py:249-260);
+* ``pytorch_transformers.optimization.AdamW(lr, eps, betas, correct_bias)`` (call site train_task.py:264-268; the
+  package is an un-vendored dependency of the reference -> parity of its arithmetic is pinned by this repo's own
+  trajectory test against a plain-python restatement, "parity unpinned" by the reference);
+* ``WarmupLinearSchedule(warmup_steps, t_total)`` (train_task.py:271-274): lr multiplier step/warmup, then linear
+  decay to 0 at t_total;
+* ``clip_grad_norm_(model.parameters(), 1.0)`` (train_task.py:330);
+* apex DDP with ``delay_allreduce=True``: ONE flat fp32 all-reduce(SUM) after backward, then * 1/world_size
+  (volta/apex/apex/parallel/distributed.py:425-475, :491-510).
+
+MI355X design: all parameters live in one flat fp32 arena (``p.data`` are views), with sibling arenas for the
+gradient and the two Adam moments.  One step = gather grads into the flat arena (multi-tensor copy), bucketed
+RCCL all-reduce directly on slices of that arena (no flatten/unflatten copies), one sum-of-squares kernel, and one
+AdamW kernel that also applies the clip coefficient (read from device memory -- no host sync) and zeroes the grads.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")
+
+
+def warmup_linear(step, warmup_steps, t_total):
+    """pytorch_transformers.WarmupLinearSchedule.lr_lambda."""
+    if step < warmup_steps:
+        return float(step) / float(max(1, warmup_steps))
+    return max(0.0, float(t_total - step) / float(max(1.0, t_total - warmup_steps)))
+
+
+def reference_param_groups(named_params, base_lr, weight_decay):
+    """[(name, param, lr, wd)] in ``named_parameters`` order (train_task.py:249-260)."""
+    out, seen = [], set()
+    for name, p in named_params:
+        if not p.requires_grad or id(p) in seen:
+            continue
+        seen.add(id(p))
+        lr = 1e-4 if "vil_" in name else base_lr
+        wd = 0.0 if any(nd in name for nd in NO_DECAY) else weight_decay
+        out.append((name, p, lr, wd))
+    return out
+
+
+class FlatArena(object):
+    """Re-homes parameters into one contiguous fp32 buffer (16-byte aligned segments)."""
+
+    def __init__(self, groups, device):
+        self.groups = groups
+        offs, total = [], 0
+        for _, p, _, _ in groups:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.offsets, self.total = offs, total
+        self.param = torch.zeros(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)
+        for (name, p, _, _), off in zip(groups, offs):
+            view = self.param[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+        self.grad_views = [self.grad[off:off + p.numel()].view_as(p) for (_, p, _, _), off in zip(groups, offs)]
+
+    def gather_grads(self):
+        """Copy the autograd-produced gradients into the flat gradient arena (params without a grad -- e.g.
+        M3P's never-used modules -- contribute zeros, like apex skipping ``grad is None``)."""
+        dst, src = [], []
+        for (_, p, _, _), gv in zip(self.groups, self.grad_views):
+            if p.grad is not None:
+                dst.append(gv)
+                src.append(p.grad)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for _, p, _, _ in self.groups:
+            p.grad = None
+
+
+class GradReducer(object):
+    """Bucketed all-reduce(SUM) of the flat gradient arena over RCCL (backend "nccl") or gloo.
+
+    Buckets are slices of the arena (no flatten / unflatten), launched asynchronously back-to-back so that RCCL
+    pipelines them over all xGMI links; the 1/world_size factor is folded into the optimizer's grad scale."""
+
+    def __init__(self, bucket_bytes=64 << 20, group=None):
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.group = group
+
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def allreduce_(self, flat):
+        ws = self.world_size()
+        if ws == 1:
+            return 1.0
+        works = []
+        for s in range(0, flat.numel(), self.bucket_elems):
+            works.append(dist.all_reduce(flat[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.group,
+                                         async_op=True))
+        for w in works:
+            w.wait()
+        return 1.0 / ws
+
+
+class FusedAdamW(object):
+    """AdamW(correct_bias) + clip + LR schedule + zero-grad as two kernels over the flat arena."""
+
+    def __init__(self, model, base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True,
+                 max_grad_norm=1.0, warmup_steps=0, t_total=None, reducer=None):
+        params = list(model.named_parameters())
+        device = params[0][1].device
+        if device.type != "cuda":
+            raise RuntimeError("clg_vqa_amd.FusedAdamW: parameters must be on the MI355X (no CPU path)")
+        self.model = model
+        self.groups = reference_param_groups(params, base_lr, weight_decay)
+        self.arena = FlatArena(self.groups, device)
+        n = self.arena.total
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=device)
+        ends = [off + (p.numel() + 3) // 4 * 4 for (_, p, _, _), off in zip(self.groups, self.arena.offsets)]
+        self.seg_end = torch.tensor(ends, dtype=torch.int64, device=device)
+        self.seg_lr = torch.tensor([g[2] for g in self.groups], dtype=torch.float32, device=device)
+        self.seg_wd = torch.tensor([g[3] for g in self.groups], dtype=torch.float32, device=device)
+        self.betas, self.eps, self.correct_bias = betas, eps, correct_bias
+        self.max_grad_norm = max_grad_norm
+        self.warmup_steps, self.t_total = warmup_steps, t_total
+        self.reducer = reducer or GradReducer()
+        self.sched_step = 0  # scheduler.step() count (train_task.py:335)
+        self.opt_step = 0
+        self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)
+        self._scale = torch.zeros(1, dtype=torch.float32, device=device)
+        if hasattr(model, "mark_weights_dirty"):
+            model.mark_weights_dirty()
+
+    def lr_mult(self):
+        if self.t_total is None:
+            return 1.0
+        return warmup_linear(self.sched_step, self.warmup_steps, self.t_total)
+
+    def step(self):
+        """reduce -> clip -> AdamW -> scheduler step -> zero_grad  (train_task.py:326-338)."""
+        a = self.arena
+        a.gather_grads()
+        post = self.reducer.allreduce_(a.grad)
+        self._sumsq.zero_()
+        ops.sumsq(a.grad, self._sumsq)
+        # clip coefficient on the device: min(1, max_norm / (||g|| + 1e-6)) with ||g|| of the averaged gradient
+        norm = self._sumsq.sqrt() * post
+        torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0, out=self._scale)
+        self._scale.mul_(post)
+        self.opt_step += 1
+        ops.adamw(a.param, a.grad, self.exp_avg, self.exp_avg_sq, self.seg_end, self.seg_lr, self.seg_wd,
+                  self.betas[0], self.betas[1], self.eps, self.opt_step, self.correct_bias, self.lr_mult(),
+                  grad_scale_dev=self._scale, zero_grad=True)
+        self.sched_step += 1
+        if hasattr(self.model, "mark_weights_dirty"):
+            self.model.mark_weights_dirty()
+        return norm

@@ -1,0 +1,82 @@
+"""world_size-2 gloo tests (CPU) of the multi-GPU host logic: flat-arena gradient reducer, the reference's
+parameter grouping and LR schedule.  The path is pure data parallelism: the only exchange is one gradient
+all-reduce(SUM) per optimizer step followed by 1/world_size (apex DDP, distributed.py:425-475)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from clg_vqa_amd.optim import FlatArena, GradReducer, reference_param_groups, warmup_linear
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)  # identical replicas
+    lin = torch.nn.Linear(37, 11)
+    ln = torch.nn.LayerNorm(11)
+    named = [("bert.x.dense.weight", lin.weight), ("bert.x.dense.bias", lin.bias),
+             ("bert.x.LayerNorm.weight", ln.weight), ("bert.x.LayerNorm.bias", ln.bias)]
+    groups = reference_param_groups(named, 4e-5, 1e-4)
+    arena = FlatArena(groups, torch.device("cpu"))
+    assert lin.weight.data_ptr() == arena.param.data_ptr()  # parameters were re-homed into the arena
+    x = torch.randn(5, 37, generator=torch.Generator().manual_seed(100 + rank))
+    ln(lin(x)).pow(2).sum().backward()
+    local = [p.grad.clone() for _, p, _, _ in groups]
+    arena.gather_grads()
+    assert all(p.grad is None for _, p, _, _ in groups)
+    post = GradReducer(bucket_bytes=256).allreduce_(arena.grad)  # tiny buckets -> several collectives
+    assert post == 1.0 / world
+    gathered = [torch.zeros_like(arena.grad) for _ in range(world)]
+    q.put((rank, [g.tolist() for g in local], arena.grad.tolist(), arena.offsets))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_arena_allreduce_world2():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, g0, flat0, offs), (_, g1, flat1, _) = res
+    assert flat0 == flat1  # both ranks hold the same reduced gradient
+    flat = torch.tensor(flat0)
+    for i, off in enumerate(offs):
+        a, b = torch.tensor(g0[i]).reshape(-1), torch.tensor(g1[i]).reshape(-1)
+        torch.testing.assert_close(flat[off:off + a.numel()], a + b, rtol=1e-6, atol=1e-6)
+
+
+def test_param_groups_and_schedule():
+    w, b = torch.nn.Parameter(torch.zeros(3, 3)), torch.nn.Parameter(torch.zeros(3))
+    named = [("bert.encoder.layer.0.attention_output.dense.weight", w),
+             ("bert.encoder.layer.0.attention_output.dense.bias", b),
+             ("bert.encoder.layer.0.attention_output.LayerNorm.weight", torch.nn.Parameter(torch.ones(3))),
+             ("vil_prediction.weight", torch.nn.Parameter(torch.ones(3))),
+             ("alias.of.w", w)]
+    g = reference_param_groups(named, 4e-5, 1e-4)
+    assert [(n, lr, wd) for n, _, lr, wd in g] == [
+        ("bert.encoder.layer.0.attention_output.dense.weight", 4e-5, 1e-4),
+        ("bert.encoder.layer.0.attention_output.dense.bias", 4e-5, 0.0),
+        ("bert.encoder.layer.0.attention_output.LayerNorm.weight", 4e-5, 0.0),
+        ("vil_prediction.weight", 1e-4, 1e-4)]
+    assert warmup_linear(0, 10, 100) == 0.0 and warmup_linear(5, 10, 100) == 0.5
+    assert warmup_linear(10, 10, 100) == 1.0 and abs(warmup_linear(55, 10, 100) - 0.5) < 1e-12
+    assert warmup_linear(100, 10, 100) == 0.0
