@@ -81,7 +81,9 @@ def cpu_baseline(seconds_budget=25.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, 16)  # a one-GPU box owns a 16-core share of the host; more threads only oversubscribe it
     torch.set_num_threads(cores)
+    print("[bench] cpu_baseline: building the oracle (UC2 full config) on %d host threads" % cores, file=sys.stderr, flush=True)
     config = BertConfig.from_dict(uc2_full_cfg())
     torch.manual_seed(0)
     model = O.OracleUC2ForVLTasks(config, TASK_CFG, ["TASK15"])
@@ -93,12 +95,13 @@ def cpu_baseline(seconds_budget=25.0):
     batch = make_batch(mb, seed=99)
     times = []
     t_start = time.time()
-    for i in range(6):
+    for i in range(4):
         t0 = time.time()
         model.zero_grad()
         loss, _, _ = O.forward_train(model, batch)
         loss.backward()
         dt = time.time() - t0
+        print("[bench] cpu_baseline: step %d took %.2f s" % (i, dt), file=sys.stderr, flush=True)
         if i > 0:
             times.append(dt)
         if time.time() - t_start > seconds_budget and len(times) >= 2:
@@ -187,7 +190,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
 
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
@@ -220,6 +223,7 @@ def main():
             "roofline": roof,
         }
         line["step_tflops"] = round(29.241e-3 * world * args.batch / (elapsed / args.steps), 2)
+        print("[bench] gpu part done: %.1f samples/s, %.2f ms/step" % (value, 1e3 * elapsed / args.steps), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             del model, opt
             torch.cuda.empty_cache()

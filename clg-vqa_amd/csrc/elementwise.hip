@@ -117,12 +117,22 @@ __global__ __launch_bounds__(256) void colsum_stage1(const bf16_raw* __restrict_
     *reinterpret_cast<float4*>(ws + (long)blockIdx.y * N + n) = s;
   }
 }
-__global__ void colsum_stage2(const float* __restrict__ ws, int nrb, int N, float* __restrict__ out) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ ws, int nrb, int N,
+                                                     float* __restrict__ out) {
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + tx;
   float s = 0.f;
-  for (int b = 0; b < nrb; ++b) s += ws[(long)b * N + n];
-  out[n] = s;
+  if (n < N)
+    for (int b = ty; b < nrb; b += 16) s += ws[(long)b * N + n];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][tx];
+    out[n] = t;
+  }
 }
 
 // ---- additive key mask over [text ; boxes] (encoders.py:978-995) --------------------------------------------
@@ -228,30 +238,50 @@ __global__ __launch_bounds__(256) void loc_bwd_kernel(const float* __restrict__ 
 // pytorch_transformers.optimization.AdamW semantics (un-vendored dependency of the reference; call site
 // train_task.py:264-268): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= step * m / (sqrt(v) + eps) with
 // step = lr (* sqrt(1-b2^t)/(1-b1^t) when correct_bias); then decoupled decay p -= lr * wd * p.
+constexpr int ADAMW_MAX_SEG = 2048;
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float* __restrict__ g,
-                                                    float* __restrict__ m, float* __restrict__ v, long n,
+                                                    float* __restrict__ m, float* __restrict__ v, long n4,
                                                     const int64_t* __restrict__ seg_end,
                                                     const float* __restrict__ seg_lr,
                                                     const float* __restrict__ seg_wd, int nseg, float b1, float b2,
                                                     float eps, float bc, float lr_mult, const float* gscale_ptr,
                                                     float gscale_const, int zero_grad) {
+  // segment table (every segment starts on a multiple of 4 elements) -> LDS, in float4 units
+  __shared__ int s_end4[ADAMW_MAX_SEG];
+  __shared__ float s_lr[ADAMW_MAX_SEG], s_wd[ADAMW_MAX_SEG];
+  for (int i = threadIdx.x; i < nseg; i += 256) {
+    s_end4[i] = (int)(seg_end[i] >> 2);
+    s_lr[i] = seg_lr[i] * lr_mult;
+    s_wd[i] = seg_wd[i];
+  }
+  __syncthreads();
   const float gs = gscale_ptr ? *gscale_ptr : gscale_const;
+  const float c1 = 1.f - b1, c2 = 1.f - b2;
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     int lo = 0, hi = nseg - 1;  // first segment whose end > i
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
-      if (seg_end[mid] > i) hi = mid; else lo = mid + 1;
+      if (s_end4[mid] > i) hi = mid; else lo = mid + 1;
     }
-    const float lr = seg_lr[lo] * lr_mult, wd = seg_wd[lo];
-    const float grad = g[i] * gs;
-    const float mi = b1 * m[i] + (1.f - b1) * grad;
-    const float vi = b2 * v[i] + (1.f - b2) * grad * grad;
-    m[i] = mi; v[i] = vi;
-    float x = p[i] - (lr * bc) * (mi / (sqrtf(vi) + eps));
-    if (wd > 0.f) x -= lr * wd * x;
-    p[i] = x;
-    if (zero_grad) g[i] = 0.f;
+    const float lr = s_lr[lo], wd = s_wd[lo], step = lr * bc, decay = 1.f - lr * wd;
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define VL_ADAM1(c)                                          \
+    {                                                        \
+      const float grad = gg.c * gs;                          \
+      mm.c = b1 * mm.c + c1 * grad;                          \
+      vv.c = b2 * vv.c + c2 * grad * grad;                   \
+      float x = pp.c - step * (mm.c / (sqrtf(vv.c) + eps)); \
+      if (wd > 0.f) x *= decay;                              \
+      pp.c = x;                                              \
+    }
+    VL_ADAM1(x) VL_ADAM1(y) VL_ADAM1(z) VL_ADAM1(w)
+#undef VL_ADAM1
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -259,7 +289,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   __shared__ float red[4];
   float s = 0.f;
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += x[i] * x[i];
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 q = reinterpret_cast<const float4*>(x)[i];
+    s += (q.x * q.x + q.y * q.y) + (q.z * q.z + q.w * q.w);
+  }
+  if (blockIdx.x == 0) {
+    const long i = n4 * 4 + threadIdx.x;
+    if (i < n) s += x[i] * x[i];
+  }
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
@@ -325,7 +363,7 @@ extern "C" int vl_colsum_bf16(const void* x16, int64_t M, int64_t N, int64_t ld,
   hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)((N + 255) / 256), (unsigned)rb), dim3(256), 0,
                      (hipStream_t)stream, (const bf16_raw*)x16, (int)M, (int)N, (long)ld, ws);
   VL_CHECK_LAUNCH("vl_colsum_bf16");
-  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ws, (int)rb,
+  hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, ws, (int)rb,
                      (int)N, out32);
   VL_CHECK_LAUNCH("vl_colsum_bf16(stage2)");
   return 0;
@@ -383,18 +421,22 @@ extern "C" int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_av
                         const float* grad_scale_dev, float grad_scale, int zero_grad, void* stream) {
   VL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && seg_end && seg_lr && seg_wd && n > 0 && nseg > 0 && step > 0,
                "vl_adamw: bad arguments");
+  VL_CHECK_ARG(nseg <= ADAMW_MAX_SEG && (n & 3) == 0 && (n >> 2) < (1LL << 31),
+               "vl_adamw: arena length must be a multiple of 4 (segments 4-aligned), nseg <= %d", ADAMW_MAX_SEG);
+  VL_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
+               "vl_adamw: arenas must be 16-byte aligned");
   float bc = 1.0f;
   if (correct_bias) bc = (float)(sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step)));
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 256 * 16)), dim3(256), 0, (hipStream_t)stream, param, grad,
-                     exp_avg, exp_avg_sq, (long)n, seg_end, seg_lr, seg_wd, (int)nseg, beta1, beta2, eps, bc, lr_mult,
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                     exp_avg, exp_avg_sq, (long)(n / 4), seg_end, seg_lr, seg_wd, (int)nseg, beta1, beta2, eps, bc, lr_mult,
                      grad_scale_dev, grad_scale, zero_grad);
   VL_CHECK_LAUNCH("vl_adamw");
   return 0;
 }
 
 extern "C" int vl_sumsq(const float* x, int64_t n, float* out, void* stream) {
-  VL_CHECK_ARG(x && out && n > 0, "vl_sumsq: bad arguments");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
+  VL_CHECK_ARG(x && out && n > 0 && ((uintptr_t)x & 15) == 0, "vl_sumsq: bad arguments (x must be 16-byte aligned)");
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out);
   VL_CHECK_LAUNCH("vl_sumsq");
   return 0;
 }

@@ -30,6 +30,7 @@ struct GemmArgs {
   const float* bias; const float* resid; float* out32; long ldc;
   bf16_raw* out_hi; bf16_raw* out_lo; bf16_raw* aux16; long ld16;
   int tiles_m, tiles_n;
+  int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -66,17 +67,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int kbeg = blockIdx.y * p.k_len;
+  const int kend = min(p.K, kbeg + p.k_len);
   uint4 ra_hi[4], rb_hi[4], ra_lo[4], rb_lo[4];
   auto load_tile = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + i * 256;
       const int row = c >> 3, k = k0 + ((c & 7) << 3);
-      ra_hi[i] = load_chunk(p.a_hi, p.lda, row0 + row, p.M, k, p.K);
-      rb_hi[i] = load_chunk(p.b_hi, p.ldb, col0 + row, p.N, k, p.K);
+      ra_hi[i] = load_chunk(p.a_hi, p.lda, row0 + row, p.M, k, kend);
+      rb_hi[i] = load_chunk(p.b_hi, p.ldb, col0 + row, p.N, k, kend);
       if (NSPLIT == 3) {
-        ra_lo[i] = load_chunk(p.a_lo, p.lda, row0 + row, p.M, k, p.K);
-        rb_lo[i] = load_chunk(p.b_lo, p.ldb, col0 + row, p.N, k, p.K);
+        ra_lo[i] = load_chunk(p.a_lo, p.lda, row0 + row, p.M, k, kend);
+        rb_lo[i] = load_chunk(p.b_lo, p.ldb, col0 + row, p.N, k, kend);
       }
     }
   };
@@ -94,14 +97,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     }
   };
 
-  const int nk = (p.K + BK - 1) / BK;
-  load_tile(0);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  load_tile(kbeg);
   const int frow = lane & 15, fk = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
     __syncthreads();  // every wave is done reading the previous tile
     store_tile();
     __syncthreads();
-    if (kt + 1 < nk) load_tile((kt + 1) * BK);  // in flight under the MFMA block below
+    if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * BK);  // in flight under the MFMA block below
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 a_h[4], b_h[4], a_l[4], b_l[4];
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   }
 
   // epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg
+  float* out32 = p.out32 + (long)blockIdx.y * p.slab_stride;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
         float v = acc[i][j][rr] + bv;
         if (EPI == VL_EPI_F32) {
           if (p.resid) v += p.resid[(long)m * p.ldc + n];
-          p.out32[(long)m * p.ldc + n] = v;
+          out32[(long)m * p.ldc + n] = v;
         } else if (EPI == VL_EPI_GELU_SPLIT) {
           p.aux16[(long)m * p.ld16 + n] = f32_to_bf16(v);
           bf16_raw hi, lo;
@@ -166,8 +170,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
     }
 }
 
+// out[i] = sum_s ws[s][i]  (float4 granularity)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int splits, long n4,
+                                                            float* __restrict__ out) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 acc = reinterpret_cast<const float4*>(ws)[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 v = reinterpret_cast<const float4*>(ws)[(long)s * n4 + i];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = acc;
+  }
+}
+
 template <int NSPLIT, int EPI>
-int launch(const GemmArgs& a, hipStream_t stream) {
+int launch(const GemmArgs& a, hipStream_t stream, int splits = 1) {
   const size_t lds = (NSPLIT == 3 ? 4 : 2) * TILE_BYTES;
   static bool attr_set = false;  // per instantiation; idempotent, so a race only repeats the call
   if (!attr_set) {
@@ -176,7 +194,7 @@ int launch(const GemmArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<NSPLIT, EPI>), dim3(a.tiles_m * a.tiles_n), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<NSPLIT, EPI>), dim3(a.tiles_m * a.tiles_n, splits), dim3(256), lds, stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt");
   return 0;
 }
@@ -227,6 +245,46 @@ extern "C" int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const
   a.bias = bias; a.resid = resid32; a.out32 = out32; a.ldc = ldc;
   a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.aux16 = (bf16_raw*)aux16; a.ld16 = ld16;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
+  a.k_len = (int)K; a.slab_stride = 0;
   hipStream_t s = (hipStream_t)stream;
   return passes == 3 ? dispatch_epi<3>(epilogue, a, s) : dispatch_epi<1>(epilogue, a, s);
+}
+
+// Split-K variant for the weight-gradient products dW[N_out,K_in] = dY^T X, whose reduction dimension is the
+// B*S = 14336 rows of the batch while the output is only 36..144 tiles: `splits` workgroups per output tile each
+// reduce a K-range into their own fp32 slab (plain stores), then one streaming pass sums the slabs (deterministic;
+// float atomics would run at ~1.3 TB/s chip-wide and are slower here).
+extern "C" int64_t vl_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t splits) { return M * N * splits; }
+
+extern "C" int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi, int64_t ldb, int64_t M, int64_t N,
+                                 int64_t K, int64_t splits, float* ws, float* out32, void* stream) {
+  VL_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && splits >= 1 && splits <= 64,
+               "vl_gemm_nt_splitk: bad dims / splits");
+  VL_CHECK_ARG(a_hi && b_hi && out32 && (splits == 1 || ws), "vl_gemm_nt_splitk: null pointer");
+  VL_CHECK_ARG((K & 7) == 0 && (lda & 7) == 0 && (ldb & 7) == 0 && lda >= K && ldb >= K && aligned16(a_hi) && aligned16(b_hi),
+               "vl_gemm_nt_splitk: K, lda, ldb must be multiples of 8, pointers 16-byte aligned");
+  VL_CHECK_ARG(splits == 1 || ((M * N) % 4 == 0 && aligned16(ws) && aligned16(out32)),
+               "vl_gemm_nt_splitk: M*N must be a multiple of 4 and ws/out32 16-byte aligned");
+  GemmArgs a{};
+  a.a_hi = (const bf16_raw*)a_hi; a.b_hi = (const bf16_raw*)b_hi;
+  a.lda = lda; a.ldb = ldb; a.M = (int)M; a.N = (int)N; a.K = (int)K;
+  a.ldc = N;
+  a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
+  int64_t k_len = (K + splits - 1) / splits;
+  k_len = (k_len + BK - 1) / BK * BK;
+  const int eff = (int)((K + k_len - 1) / k_len);
+  a.k_len = (int)k_len;
+  hipStream_t s = (hipStream_t)stream;
+  if (eff == 1) {
+    a.out32 = out32; a.slab_stride = 0;
+    return launch<1, VL_EPI_F32>(a, s, 1);
+  }
+  a.out32 = ws; a.slab_stride = M * N;
+  if (int rc = launch<1, VL_EPI_F32>(a, s, eff)) return rc;
+  const long n4 = (long)(M * N / 4);
+  long g = (n4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, ws, eff, n4, out32);
+  VL_CHECK_LAUNCH("vl_gemm_nt_splitk(reduce)");
+  return 0;
 }

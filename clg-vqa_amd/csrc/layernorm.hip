@@ -179,16 +179,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
   }
 }
 
-// out_k[c] = sum_blk ws[blk][k][c]
-__global__ void ln_bwd_reduce_kernel(const float* ws, int nblk, int H, float* dgamma, float* dbeta, float* dbias) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= 3 * H) return;
-  const int k = idx / H, c = idx - k * H;
-  float* dst = k == 0 ? dgamma : (k == 1 ? dbeta : dbias);
-  if (!dst) return;
+// out_k[c] = sum_blk ws[blk][k][c]; 256 threads = 16 columns x 16 row-groups, LDS combine
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int H,
+                                                            float* dgamma, float* dbeta, float* dbias) {
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int idx = blockIdx.x * 16 + tx;  // column in [0, 3H)
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += ws[((long)b * 3 + k) * H + c];
-  dst[c] = s;
+  if (idx < 3 * H)
+    for (int b = ty; b < nblk; b += 16) s += ws[(long)b * 3 * H + idx];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && idx < 3 * H) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][tx];
+    const int k = idx / H, c = idx - k * H;
+    float* dst = k == 0 ? dgamma : (k == 1 ? dbeta : dbias);
+    if (dst) dst[c] = t;
+  }
 }
 
 int nblk_for(int64_t M) {
@@ -208,7 +217,7 @@ template <int NV>
 int launch_bwd(const LnArgs& a, hipStream_t s, float* dgamma, float* dbeta, float* dbias) {
   hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(a.nblk), dim3(256), 0, s, a);
   VL_CHECK_LAUNCH("vl_ln_bwd");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * a.H + 255) / 256), dim3(256), 0, s, a.ws, a.nblk, a.H,
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * a.H + 15) / 16), dim3(256), 0, s, a.ws, a.nblk, a.H,
                      dgamma, dbeta, dbias);
   VL_CHECK_LAUNCH("vl_ln_bwd(reduce)");
   return 0;

@@ -81,7 +81,7 @@ def dw_gemm(dy16, x16, M, N, K):
     ops.transpose_bf16(dy16, dyT, M, N)
     ops.transpose_bf16(x16, xT, M, K)
     dW = torch.empty(N, K, dtype=torch.float32, device=dev)
-    ops.gemm_nt(dyT, None, xT, None, N, K, Mp, 1, EPI_F32, out32=dW)
+    ops.gemm_nt_splitk(dyT, xT, N, K, Mp, dW)
     return dW
 
 

@@ -51,6 +51,20 @@ def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=
                                      _stream()), "vl_gemm_nt")
 
 
+def gemm_nt_splitk(a_hi, b_hi, M, N, K, out32, target_wgs=640):
+    """out32[M,N] = A[M,K] . B[N,K]^T with the K range split over enough workgroups to fill the 256 CUs."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    splits = max(1, min(32, (target_wgs + tiles // 2) // tiles, (K + 63) // 64))
+    ws = None
+    if splits > 1:
+        ws = torch.empty(_lib.lib().vl_gemm_splitk_ws_floats(M, N, splits), dtype=torch.float32, device=out32.device)
+    pa, lda = _pld(a_hi)
+    pb, ldb = _pld(b_hi)
+    assert out32.is_contiguous() and out32.shape[-1] == N
+    _lib.check(_lib.lib().vl_gemm_nt_splitk(pa, lda, pb, ldb, M, N, K, splits, _p(ws), _p(out32), _stream()),
+               "vl_gemm_nt_splitk")
+
+
 def attn_fwd(qkv32, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed):
     _lib.check(_lib.lib().vl_attn_fwd(_p(qkv32), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
                                       float(p_drop), int(seed), _stream()), "vl_attn_fwd")

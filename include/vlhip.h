@@ -49,6 +49,13 @@ int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi
                int64_t M, int64_t N, int64_t K, int passes, int epilogue, const float* bias, const float* resid32,
                float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream);
 
+/* Split-K form for the weight gradients dW[M,N] = A[M,K] * B[N,K]^T with K = B*S rows (bf16 single pass, fp32 out,
+ * ld = N): `splits` K-ranges accumulate into fp32 slabs in `ws` (>= vl_gemm_splitk_ws_floats floats), then one
+ * streaming pass sums them into out32 (deterministic, no atomics). */
+int64_t vl_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t splits);
+int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                      int64_t splits, float* ws, float* out32, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused V&L attention core over the single stream X = [text ; boxes]  (S = T + V <= 160, head dim 64).
  * Replaces encoders.py:255-341: four gated score blocks, two concatenated softmaxes, four dropouts, four P.V

@@ -73,6 +73,16 @@ def test_gemm_three_pass_is_fp32_grade(M, N, K):
     assert err < err1 / 20, (err, err1)
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 768, 14336), (2304, 768, 14336), (768, 3072, 4096), (200, 136, 1000), (128, 128, 64)])
+def test_gemm_splitk(M, N, K):
+    a = _rand(M, K, seed=40).to(BF16)
+    b = _rand(N, K, seed=41).to(BF16)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_nt_splitk(a, b, M, N, K, out)
+    ref = (a.double() @ b.double().t()).float()
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(K / 256))
+
+
 def test_gemm_epilogues():
     M, N, K = 384, 512, 256
     x, w, bias = _rand(M, K, seed=9), _rand(N, K, seed=10, scale=0.1), _rand(N, seed=11)
@@ -333,13 +343,13 @@ def test_adamw_and_sumsq():
     n = 5000
     p, g = _rand(n, seed=37), _rand(n, seed=38)
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
-    seg_end = torch.tensor([1000, 1003, 5000], dtype=torch.int64, device=DEV)
+    seg_end = torch.tensor([1000, 1004, 5000], dtype=torch.int64, device=DEV)
     seg_lr = torch.tensor([4e-5, 1e-4, 4e-5], device=DEV)
     seg_wd = torch.tensor([1e-4, 0.0, 1e-4], device=DEV)
     p0, g0 = p.double().cpu(), g.double().cpu()
     rp, rm, rv = p0.clone(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
-    lr = torch.cat([torch.full((1000,), 4e-5), torch.full((3,), 1e-4), torch.full((3997,), 4e-5)]).double()
-    wd = torch.cat([torch.full((1000,), 1e-4), torch.zeros(3), torch.full((3997,), 1e-4)]).double()
+    lr = torch.cat([torch.full((1000,), 4e-5), torch.full((4,), 1e-4), torch.full((3996,), 4e-5)]).double()
+    wd = torch.cat([torch.full((1000,), 1e-4), torch.zeros(4), torch.full((3996,), 1e-4)]).double()
     b1, b2, eps, lr_mult, gs = 0.9, 0.999, 1e-6, 0.5, 0.7
     for step in (1, 2, 3):
         ops.adamw(p, g, m, v, seg_end, seg_lr, seg_wd, b1, b2, eps, step, True, lr_mult, None, gs, False)
