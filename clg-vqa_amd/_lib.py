@@ -16,8 +16,10 @@ P = c_void_p
 _SIGS = {
     "vl_version": (c_int, []),
     "vl_last_error": (c_char_p, []),
+    "vl_debug_set": (c_int, [c_int, c_int]),
     "vl_gemm_nt": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, P, P, P, c_int64,
                            P, P, P, c_int64, P]),
+    "vl_gemm_splitk_plan": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_splitk_ws_floats": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_nt_splitk": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P]),
     "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),

@@ -30,12 +30,29 @@ __device__ __forceinline__ void split_bf16(float x, bf16_raw& hi, bf16_raw& lo) 
   lo = f32_to_bf16(x - bf16_to_f32(hi));
 }
 
-// ---- exact-erf GELU (reference volta/encoders.py:131-137) ---------------------------------------
-__device__ __forceinline__ float gelu_erf(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752f)); }
+// ---- erf-GELU (reference volta/encoders.py:131-137: x * 0.5 * (1 + erf(x / sqrt 2))) -----------------------------
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-grade for the activation): one v_exp + one v_rcp
+// instead of libm's ~40-instruction erff.  exp(-x^2/2) is shared between the cdf and the pdf in the gradient.
+__device__ __forceinline__ void vl_cdf_pdf(float x, float& cdf, float& e) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  e = __expf(-0.5f * x * x);  // = exp(-(x/sqrt2)^2)
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float h = 0.5f * poly * t * e;        // 0.5 * (1 - erf(|x|/sqrt2))
+  cdf = x >= 0.f ? 1.0f - h : h;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float cdf, e;
+  vl_cdf_pdf(x, cdf, e);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, e;
+  vl_cdf_pdf(x, cdf, e);
+  return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 
 // ---- counter-based RNG for dropout ------------------------------------------------------------

@@ -9,7 +9,17 @@
 //   passes = 3   operands given as (hi, lo) bf16 pairs with x ~= hi + lo (16 significant bits);
 //                acc += Alo*Bhi + Ahi*Blo + Ahi*Bhi        -> fp32-grade forward (logits within 1e-3)
 //
-// Tiling: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
+// Two kernels share the epilogues:
+//  * gemm2_kernel (fast path, K % 64 == 0 / % 32 for 3-pass, M >= 256): 256 x BN output tile (BN = 256 / 192 / 128
+//    picked per shape so the tile count fills the 256 CUs), 512 threads = 8 waves as 2(M) x 4(N), operand tiles
+//    DMA'd global -> LDS with global_load_lds_dwordx4 (no VGPR staging, no ds_write), two LDS stages so the next
+//    K-step's DMA flies under the current step's MFMAs, one barrier per K-step.  The LDS image is lane-linear per
+//    DMA instruction (1 KiB = 8 rows x 128 B); the bank-conflict-free XOR swizzle is applied to the per-lane SOURCE
+//    address and undone by the ds_read_b128 fragment reads.  For the 3-pass mode a 128-byte LDS row holds
+//    [hi k0..31 | lo k0..31], so both modes share one image / one set of addresses.
+//  * gemm_nt_kernel (generic path, any K multiple of 8): described next.
+//
+// Tiling (generic path): 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave = 4x4 MFMA
 // tiles), BK = 64.  Operands are K-contiguous; tiles are staged global -> registers -> LDS with an XOR
 // swizzle of the 16-byte chunk index ((row>>1)&7) so that every ds_read_b128 fragment read is
 // bank-conflict free on the 64-bank LDS; the next tile's global loads are issued before the MFMA block
@@ -30,6 +40,7 @@ struct GemmArgs {
   const float* bias; const float* resid; float* out32; long ldc;
   bf16_raw* out_hi; bf16_raw* out_lo; bf16_raw* aux16; long ld16;
   int tiles_m, tiles_n;
+  int vec;                      // 1: leading dimensions / pointers allow the 16-byte (fp32) / 8-byte (bf16) epilogue
   int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
 };
 
@@ -40,6 +51,219 @@ __device__ __forceinline__ uint4 load_chunk(const bf16_raw* base, long ld, int r
   return make_uint4(0u, 0u, 0u, 0u);
 }
 
+// Epilogue for 4 consecutive output columns n0..n0+3 of row m (the MFMA is issued as D^T = B.A^T so that a lane's
+// 4 accumulator registers are 4 consecutive n: 16-byte fp32 / 8-byte bf16 accesses instead of scalar ones).
+template <int EPI>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32, int m, int n0, f32x4 v) {
+  const bool vec = p.vec && (n0 + 3 < p.N);
+  if (vec) {
+    if (p.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (EPI == VL_EPI_F32) {
+      const long o = (long)m * p.ldc + n0;
+      if (p.resid) {
+        const float4 r = *reinterpret_cast<const float4*>(p.resid + o);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+      }
+      *reinterpret_cast<float4*>(out32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+      const long o = (long)m * p.ld16 + n0;
+      ushort4 hi, lo;
+      if (EPI == VL_EPI_GELU_SPLIT) {
+        ushort4 u;
+        u.x = f32_to_bf16(v[0]); u.y = f32_to_bf16(v[1]); u.z = f32_to_bf16(v[2]); u.w = f32_to_bf16(v[3]);
+        *reinterpret_cast<ushort4*>(p.aux16 + o) = u;
+        split_bf16(gelu_erf(v[0]), hi.x, lo.x); split_bf16(gelu_erf(v[1]), hi.y, lo.y);
+        split_bf16(gelu_erf(v[2]), hi.z, lo.z); split_bf16(gelu_erf(v[3]), hi.w, lo.w);
+        *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
+        *reinterpret_cast<ushort4*>(p.out_lo + o) = lo;
+      } else if (EPI == VL_EPI_DGELU_BF16) {
+        const ushort4 u = *reinterpret_cast<const ushort4*>(p.aux16 + o);
+        hi.x = f32_to_bf16(v[0] * gelu_erf_grad(bf16_to_f32(u.x)));
+        hi.y = f32_to_bf16(v[1] * gelu_erf_grad(bf16_to_f32(u.y)));
+        hi.z = f32_to_bf16(v[2] * gelu_erf_grad(bf16_to_f32(u.z)));
+        hi.w = f32_to_bf16(v[3] * gelu_erf_grad(bf16_to_f32(u.w)));
+        *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
+      } else if (EPI == VL_EPI_BF16) {
+        hi.x = f32_to_bf16(v[0]); hi.y = f32_to_bf16(v[1]); hi.z = f32_to_bf16(v[2]); hi.w = f32_to_bf16(v[3]);
+        *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
+      } else {  // VL_EPI_SPLIT
+        split_bf16(v[0], hi.x, lo.x); split_bf16(v[1], hi.y, lo.y);
+        split_bf16(v[2], hi.z, lo.z); split_bf16(v[3], hi.w, lo.w);
+        *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
+        *reinterpret_cast<ushort4*>(p.out_lo + o) = lo;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {  // ragged edge / unaligned leading dimension: scalar path
+    const int n = n0 + r;
+    if (n >= p.N) break;
+    float x = v[r] + (p.bias ? p.bias[n] : 0.f);
+    if (EPI == VL_EPI_F32) {
+      if (p.resid) x += p.resid[(long)m * p.ldc + n];
+      out32[(long)m * p.ldc + n] = x;
+    } else if (EPI == VL_EPI_GELU_SPLIT) {
+      p.aux16[(long)m * p.ld16 + n] = f32_to_bf16(x);
+      bf16_raw hi, lo;
+      split_bf16(gelu_erf(x), hi, lo);
+      p.out_hi[(long)m * p.ld16 + n] = hi;
+      p.out_lo[(long)m * p.ld16 + n] = lo;
+    } else if (EPI == VL_EPI_DGELU_BF16) {
+      const float u = bf16_to_f32(p.aux16[(long)m * p.ld16 + n]);
+      p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(x * gelu_erf_grad(u));
+    } else if (EPI == VL_EPI_BF16) {
+      p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(x);
+    } else {
+      bf16_raw hi, lo;
+      split_bf16(x, hi, lo);
+      p.out_hi[(long)m * p.ld16 + n] = hi;
+      p.out_lo[(long)m * p.ld16 + n] = lo;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fast path: 256 x BN tile, LDS-DMA staging, double-buffered
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int NSPLIT, int EPI, int BN>
+__global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs p) {
+  constexpr int BM2 = 256, NT = BN / 64;                  // 16-wide n-tiles per wave (wave tile 128 x BN/4)
+  constexpr int A_UNITS = BM2 / 8, UNITS = (BM2 + BN) / 8;  // 1-KiB DMA units (8 rows x 128 B) per stage
+  constexpr int UPW = UNITS / 8;                           // units per wave
+  constexpr int STAGE = UNITS * 1024;
+  constexpr int KSTEP = NSPLIT == 3 ? 32 : 64;             // k elements consumed per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tm = swz / p.tiles_n, tn = swz - tm * p.tiles_n;
+  const int row0 = tm * BM2, col0 = tn * BN;
+  const int kbeg = blockIdx.y * p.k_len;
+  const int kend = min(p.K, kbeg + p.k_len);
+  const int nk = (kend - kbeg) / KSTEP;
+
+  // per-lane DMA source pointers: unit u = wave + 8*j covers tile rows [8u', 8u'+8) of A (u < A_UNITS) or B
+  const bf16_raw* src[UPW];
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wave + 8 * j;
+    const bool isB = u >= A_UNITS;
+    const int trow = (isB ? u - A_UNITS : u) * 8 + (lane >> 3);
+    int grow = (isB ? col0 : row0) + trow;
+    const int lim = (isB ? p.N : p.M) - 1;
+    grow = grow < lim ? grow : lim;  // rows past the edge re-read the last row; their products are never stored
+    const int lc = (lane & 7) ^ ((trow >> 1) & 7);  // logical 16-B chunk that lands at physical position lane&7
+    const bf16_raw* base;
+    int koff;
+    if (NSPLIT == 3) {
+      base = isB ? ((lc & 4) ? p.b_lo : p.b_hi) : ((lc & 4) ? p.a_lo : p.a_hi);
+      koff = (lc & 3) * 8;
+    } else {
+      base = isB ? p.b_hi : p.a_hi;
+      koff = lc * 8;
+    }
+    src[j] = base + (long)grow * (isB ? p.ldb : p.lda) + kbeg + koff;
+  }
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int j = 0; j < UPW; ++j)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + kt * KSTEP),
+                                       (lds_ptr_t)(smem + stage * STAGE + (wave + 8 * j) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  // fragment byte offsets inside a stage (row-dependent swizzle folded in); chunk index is XORed per read
+  int a_off[8], a_sw[8], b_off[NT], b_sw[NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = wm * 128 + i * 16 + frow;
+    a_off[i] = row * 128;
+    a_sw[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int row = wn * (BN / 4) + j * 16 + frow;
+    b_off[j] = A_UNITS * 1024 + row * 128;
+    b_sw[j] = (row >> 1) & 7;
+  }
+
+  issue(0, 0);
+  __syncthreads();  // waits vmcnt(0) for the DMA, then the workgroup barrier
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    if (NSPLIT == 1) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 b[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          b[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + (((kk * 4 + fk) ^ b_sw[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(st + a_off[i] + (((kk * 4 + fk) ^ a_sw[i]) << 4));
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[i][j], 0, 0, 0);
+        }
+      }
+    } else {
+      bf16x8 bh[NT], bl[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + ((fk ^ b_sw[j]) << 4));
+        bl[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + (((4 + fk) ^ b_sw[j]) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(st + a_off[i] + ((fk ^ a_sw[i]) << 4));
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(st + a_off[i] + (((4 + fk) ^ a_sw[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah, acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // next stage landed (vmcnt(0)) and everyone is done reading this one
+  }
+
+  // epilogue.  D^T layout: lane&15 -> m inside the 16-row tile, 4*(lane>>4) + reg -> n inside the 16-col tile
+  float* out32 = p.out32 + (long)blockIdx.y * p.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = row0 + wm * 128 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n0 = col0 + wn * (BN / 4) + j * 16 + 4 * (lane >> 4);
+      if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[i][j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// generic path
+// ---------------------------------------------------------------------------------------------------------------
 template <int NSPLIT, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -124,50 +348,26 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if (NSPLIT == 3) {  // small cross terms first, dominant term last
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_l[i], b_h[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h[i], b_l[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_h[j], a_l[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_l[j], a_h[i], acc[i][j], 0, 0, 0);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_h[i], b_h[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_h[j], a_h[i], acc[i][j], 0, 0, 0);
         }
     }
   }
 
-  // epilogue: C/D layout of 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + reg
+  // epilogue (D^T layout, see epilogue_store4)
   float* out32 = p.out32 + (long)blockIdx.y * p.slab_stride;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
+    const int m = row0 + wm * 64 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = col0 + wn * 64 + j * 16 + (lane & 15);
-      if (n >= p.N) continue;
-      const float bv = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int m = row0 + wm * 64 + i * 16 + 4 * (lane >> 4) + rr;
-        if (m >= p.M) continue;
-        float v = acc[i][j][rr] + bv;
-        if (EPI == VL_EPI_F32) {
-          if (p.resid) v += p.resid[(long)m * p.ldc + n];
-          out32[(long)m * p.ldc + n] = v;
-        } else if (EPI == VL_EPI_GELU_SPLIT) {
-          p.aux16[(long)m * p.ld16 + n] = f32_to_bf16(v);
-          bf16_raw hi, lo;
-          split_bf16(gelu_erf(v), hi, lo);
-          p.out_hi[(long)m * p.ld16 + n] = hi;
-          p.out_lo[(long)m * p.ld16 + n] = lo;
-        } else if (EPI == VL_EPI_DGELU_BF16) {
-          const float u = bf16_to_f32(p.aux16[(long)m * p.ld16 + n]);
-          p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(v * gelu_erf_grad(u));
-        } else if (EPI == VL_EPI_BF16) {
-          p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(v);
-        } else {  // VL_EPI_SPLIT
-          bf16_raw hi, lo;
-          split_bf16(v, hi, lo);
-          p.out_hi[(long)m * p.ld16 + n] = hi;
-          p.out_lo[(long)m * p.ld16 + n] = lo;
-        }
-      }
+      const int n0 = col0 + wn * 64 + j * 16 + 4 * (lane >> 4);
+      if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[i][j]);
     }
+  }
 }
 
 // out[i] = sum_s ws[s][i]  (float4 granularity)
@@ -199,14 +399,67 @@ int launch(const GemmArgs& a, hipStream_t stream, int splits = 1) {
   return 0;
 }
 
+template <int NSPLIT, int EPI, int BN>
+int launch2(GemmArgs a, hipStream_t stream, int splits) {
+  const size_t lds = 2 * ((256 + BN) / 8) * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, BN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + BN - 1) / BN;
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, BN>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+  VL_CHECK_LAUNCH("vl_gemm_nt(fast)");
+  return 0;
+}
+
+int g_force_bn = 0;       // tuning knobs (vl_debug_set): 0 = automatic
+int g_force_generic = 0;
+
+// BN for the fast path: fewest "rounds x tile width" over the 256 CUs (one 512-thread workgroup per CU)
+inline int pick_bn(int64_t M, int64_t N, int splits) {
+  const int64_t tm = (M + 255) / 256;
+  int best = 256;
+  int64_t best_cost = -1;
+  if (g_force_bn == 256 || g_force_bn == 192 || g_force_bn == 128) return g_force_bn;
+  const int cands[3] = {256, 192, 128};
+  for (int c = 0; c < 3; ++c) {
+    const int bn = cands[c];
+    const int64_t tiles = tm * ((N + bn - 1) / bn) * splits;
+    const int64_t cost = ((tiles + 255) / 256) * bn;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = bn; }
+  }
+  return best;
+}
+
+inline bool fast_ok(int64_t M, int64_t K, int64_t k_len, int passes) {
+  const int ks = passes == 3 ? 32 : 64;
+  return !g_force_generic && M >= 256 && (K % ks) == 0 && (k_len % ks) == 0;
+}
+
+template <int NSPLIT, int EPI>
+int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
+  if (fast_ok(a.M, a.K, a.k_len, NSPLIT)) {
+    switch (pick_bn(a.M, a.N, splits)) {
+      case 256: return launch2<NSPLIT, EPI, 256>(a, s, splits);
+      case 192: return launch2<NSPLIT, EPI, 192>(a, s, splits);
+      default: return launch2<NSPLIT, EPI, 128>(a, s, splits);
+    }
+  }
+  return launch<NSPLIT, EPI>(a, s, splits);
+}
+
 template <int NSPLIT>
 int dispatch_epi(int epi, const GemmArgs& a, hipStream_t s) {
   switch (epi) {
-    case VL_EPI_F32: return launch<NSPLIT, VL_EPI_F32>(a, s);
-    case VL_EPI_GELU_SPLIT: return launch<NSPLIT, VL_EPI_GELU_SPLIT>(a, s);
-    case VL_EPI_DGELU_BF16: return launch<NSPLIT, VL_EPI_DGELU_BF16>(a, s);
-    case VL_EPI_BF16: return launch<NSPLIT, VL_EPI_BF16>(a, s);
-    case VL_EPI_SPLIT: return launch<NSPLIT, VL_EPI_SPLIT>(a, s);
+    case VL_EPI_F32: return launch_any<NSPLIT, VL_EPI_F32>(a, s);
+    case VL_EPI_GELU_SPLIT: return launch_any<NSPLIT, VL_EPI_GELU_SPLIT>(a, s);
+    case VL_EPI_DGELU_BF16: return launch_any<NSPLIT, VL_EPI_DGELU_BF16>(a, s);
+    case VL_EPI_BF16: return launch_any<NSPLIT, VL_EPI_BF16>(a, s);
+    case VL_EPI_SPLIT: return launch_any<NSPLIT, VL_EPI_SPLIT>(a, s);
   }
   return vl_set_error(-1, "vl_gemm_nt: unknown epilogue %d", epi);
 }
@@ -246,6 +499,9 @@ extern "C" int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const
   a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.aux16 = (bf16_raw*)aux16; a.ld16 = ld16;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   a.k_len = (int)K; a.slab_stride = 0;
+  a.vec = ((ldc | ld16) & 3) == 0 && aligned16(bias) && aligned16(resid32) && aligned16(out32) &&
+          ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo) |
+            reinterpret_cast<uintptr_t>(aux16)) & 7) == 0;
   hipStream_t s = (hipStream_t)stream;
   return passes == 3 ? dispatch_epi<3>(epilogue, a, s) : dispatch_epi<1>(epilogue, a, s);
 }
@@ -254,6 +510,23 @@ extern "C" int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const
 // B*S = 14336 rows of the batch while the output is only 36..144 tiles: `splits` workgroups per output tile each
 // reduce a K-range into their own fp32 slab (plain stores), then one streaming pass sums the slabs (deterministic;
 // float atomics would run at ~1.3 TB/s chip-wide and are slower here).
+// splits so that (output tiles x splits) just fills the 256 CUs once with the fast path's 256 x BN tiles
+extern "C" int64_t vl_gemm_splitk_plan(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  int64_t best = 1;
+  if (M >= 256 && K % 64 == 0) {
+    const int64_t tiles = ((M + 255) / 256) * ((N + 191) / 192);
+    best = 256 / tiles;
+  } else {
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    best = 640 / tiles;
+  }
+  const int64_t kmax = K / 256 > 0 ? K / 256 : 1;  // at least 4 K-steps per split
+  if (best > kmax) best = kmax;
+  if (best > 32) best = 32;
+  if (best < 1) best = 1;
+  return best;
+}
 extern "C" int64_t vl_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t splits) { return M * N * splits; }
 
 extern "C" int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi, int64_t ldb, int64_t M, int64_t N,
@@ -269,6 +542,7 @@ extern "C" int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi
   a.a_hi = (const bf16_raw*)a_hi; a.b_hi = (const bf16_raw*)b_hi;
   a.lda = lda; a.ldb = ldb; a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.ldc = N;
+  a.vec = (N & 3) == 0 && aligned16(out32) && aligned16(ws);
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   int64_t k_len = (K + splits - 1) / splits;
   k_len = (k_len + BK - 1) / BK * BK;
@@ -276,15 +550,24 @@ extern "C" int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi
   a.k_len = (int)k_len;
   hipStream_t s = (hipStream_t)stream;
   if (eff == 1) {
-    a.out32 = out32; a.slab_stride = 0;
-    return launch<1, VL_EPI_F32>(a, s, 1);
+    a.out32 = out32; a.slab_stride = 0; a.k_len = (int)K;
+    return launch_any<1, VL_EPI_F32>(a, s, 1);
   }
   a.out32 = ws; a.slab_stride = M * N;
-  if (int rc = launch<1, VL_EPI_F32>(a, s, eff)) return rc;
+  if (int rc = launch_any<1, VL_EPI_F32>(a, s, eff)) return rc;
   const long n4 = (long)(M * N / 4);
   long g = (n4 + 255) / 256;
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, ws, eff, n4, out32);
   VL_CHECK_LAUNCH("vl_gemm_nt_splitk(reduce)");
+  return 0;
+}
+
+// Tuning / A-B knobs for benchmarking (not part of the drop-in surface): key 1 = force BN of the fast GEMM path
+// (0 = auto), key 2 = force the generic 128x128 kernel.
+extern "C" int vl_debug_set(int key, int value) {
+  if (key == 1) g_force_bn = value;
+  else if (key == 2) g_force_generic = value;
+  else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
   return 0;
 }

@@ -51,17 +51,18 @@ def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=
                                      _stream()), "vl_gemm_nt")
 
 
-def gemm_nt_splitk(a_hi, b_hi, M, N, K, out32, target_wgs=640):
+def gemm_nt_splitk(a_hi, b_hi, M, N, K, out32, splits=None):
     """out32[M,N] = A[M,K] . B[N,K]^T with the K range split over enough workgroups to fill the 256 CUs."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    splits = max(1, min(32, (target_wgs + tiles // 2) // tiles, (K + 63) // 64))
+    L = _lib.lib()
+    if splits is None:
+        splits = L.vl_gemm_splitk_plan(M, N, K)
     ws = None
     if splits > 1:
-        ws = torch.empty(_lib.lib().vl_gemm_splitk_ws_floats(M, N, splits), dtype=torch.float32, device=out32.device)
+        ws = torch.empty(L.vl_gemm_splitk_ws_floats(M, N, splits), dtype=torch.float32, device=out32.device)
     pa, lda = _pld(a_hi)
     pb, ldb = _pld(b_hi)
     assert out32.is_contiguous() and out32.shape[-1] == N
-    _lib.check(_lib.lib().vl_gemm_nt_splitk(pa, lda, pb, ldb, M, N, K, splits, _p(ws), _p(out32), _stream()),
+    _lib.check(L.vl_gemm_nt_splitk(pa, lda, pb, ldb, M, N, K, splits, _p(ws), _p(out32), _stream()),
                "vl_gemm_nt_splitk")
 
 

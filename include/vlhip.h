@@ -29,6 +29,7 @@ extern "C" {
 
 int vl_version(void);
 const char* vl_last_error(void);
+int vl_debug_set(int key, int value); /* benchmarking knobs: 1 = force GEMM tile BN (0 auto), 2 = force generic GEMM */
 
 /* ------------------------------------------------------------------------------------------------------------
  * GEMM  C[M,N] = A[M,K] * B[N,K]^T  (+ epilogue), bf16 MFMA with fp32 accumulation.
@@ -52,6 +53,7 @@ int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi
 /* Split-K form for the weight gradients dW[M,N] = A[M,K] * B[N,K]^T with K = B*S rows (bf16 single pass, fp32 out,
  * ld = N): `splits` K-ranges accumulate into fp32 slabs in `ws` (>= vl_gemm_splitk_ws_floats floats), then one
  * streaming pass sums them into out32 (deterministic, no atomics). */
+int64_t vl_gemm_splitk_plan(int64_t M, int64_t N, int64_t K); /* recommended number of splits for this shape */
 int64_t vl_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t splits);
 int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float* ws, float* out32, void* stream);

@@ -39,7 +39,8 @@ def test_split_reconstructs_16_bits():
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (128, 128, 64), (300, 200, 264), (1024, 768, 768),
-                                   (256, 1842, 768), (17, 9, 8), (512, 3072, 768), (512, 768, 3072)])
+                                   (256, 1842, 768), (17, 9, 8), (512, 3072, 768), (512, 768, 3072), (700, 1000, 320),
+                                   (257, 129, 64), (1000, 200, 128)])
 def test_gemm_single_pass_bf16(M, N, K):
     a = _rand(M, K, seed=2).to(BF16)
     b = _rand(N, K, seed=3).to(BF16)
@@ -52,7 +53,7 @@ def test_gemm_single_pass_bf16(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 200, 264), (1024, 2304, 768), (256, 1842, 768),
-                                   (512, 768, 3072), (700, 768, 2048)])
+                                   (512, 768, 3072), (700, 768, 2048), (300, 200, 96), (999, 333, 32)])
 def test_gemm_three_pass_is_fp32_grade(M, N, K):
     x = _rand(M, K, seed=5)
     w = _rand(N, K, seed=6, scale=0.05)

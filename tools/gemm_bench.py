@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of vl_gemm_nt on the step's GEMM shapes (run on the GPU box).  Interleaved A/B rounds in one
+process (cdna guide rule 24); random operands (rule 25)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clg_vqa_amd import _lib, ops  # noqa: E402
+from clg_vqa_amd.ops import BF16, EPI_F32  # noqa: E402
+
+DEV = "cuda"
+
+
+def bench(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    L = _lib.lib()
+    shapes = [("qkv   fwd", 14336, 2304, 768), ("oproj fwd", 14336, 768, 768), ("ffn1  fwd", 14336, 3072, 768),
+              ("ffn2  fwd", 14336, 768, 3072), ("small-A  ", 2048, 768, 3072)]
+    variants = [("generic", dict(g=1, bn=0)), ("bn256", dict(g=0, bn=256)), ("bn192", dict(g=0, bn=192)),
+                ("bn128", dict(g=0, bn=128))]
+    for passes in (1, 3):
+        print("== passes %d ==" % passes)
+        for name, M, N, K in shapes:
+            a = torch.randn(M, K, device=DEV).to(BF16)
+            al = torch.randn(M, K, device=DEV).to(BF16)
+            b = torch.randn(N, K, device=DEV).to(BF16)
+            bl = torch.randn(N, K, device=DEV).to(BF16)
+            out = torch.empty(M, N, device=DEV)
+            row = []
+            for vname, v in variants:
+                L.vl_debug_set(2, v["g"])
+                L.vl_debug_set(1, v["bn"])
+                us = bench(lambda: ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, out32=out))
+                row.append("%s %7.1f us %6.0f TF" % (vname, us, 2.0 * M * N * K / us / 1e6))
+            print("%s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
+    L.vl_debug_set(1, 0)
+    L.vl_debug_set(2, 0)
+
+
+if __name__ == "__main__":
+    main()
