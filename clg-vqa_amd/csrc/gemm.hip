@@ -262,6 +262,119 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// TN fast path for the weight gradients: C[M,N] = A^T B with A [K][M], B [K][N] both "k-strided" (row = one of the
+// B*S batch rows), i.e. dW = dY^T X straight from the row-major activations -- no transposed copies.  Same 256 x BN
+// tile / 8 waves / LDS-DMA double buffer as gemm2_kernel; the LDS image is [k][cols] and MFMA fragments (8 k-values
+// of one column per lane) are gathered with ds_read_b64_tr_b16 (two 4(k) x 16(col) transposed block reads per
+// fragment).  32-byte column blocks are XOR-swizzled with h(k) = (k&3) | ((k>>3)&1)<<2 (applied on the DMA source
+// address, undone by the reads) so that the 8 k-rows a 32-lane half touches hit 8 different 32-byte bank groups.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int BN>
+__global__ __launch_bounds__(512, 2) void gemm2_tn_kernel(GemmArgs p) {
+  constexpr int BM2 = 256, NT = BN / 64;
+  constexpr int A_ROWB = BM2 * 2, B_ROWB = BN * 2;          // bytes per k-row of the A / B tile
+  constexpr int A_UNITS = 64 * A_ROWB / 1024, B_UNITS = 64 * B_ROWB / 1024, UNITS = A_UNITS + B_UNITS;
+  constexpr int UPW = UNITS / 8, STAGE = UNITS * 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = swz / p.tiles_n, tn = swz - tm * p.tiles_n;
+  const int row0 = tm * BM2, col0 = tn * BN;
+  const int kbeg = blockIdx.y * p.k_len;
+  const int kend = min(p.K, kbeg + p.k_len);
+  const int nk = (kend - kbeg) / 64;
+
+  const bf16_raw* src[UPW];
+#pragma unroll
+  for (int j = 0; j < UPW; ++j) {
+    const int u = wave + 8 * j;
+    const bool isB = u >= A_UNITS;
+    const int rowb = isB ? B_ROWB : A_ROWB;
+    const int cpr = rowb / 16;                         // 16-byte chunks per k-row (32 or 16)
+    const int k = (isB ? u - A_UNITS : u) * (1024 / rowb) + lane / cpr;
+    const int c = lane % cpr;
+    const int lb = (c >> 1) ^ ((k & 3) | (((k >> 3) & 1) << 2));  // logical 32-B block landing at physical c>>1
+    int gcol = (isB ? col0 : row0) + lb * 16 + (c & 1) * 8;
+    const int lim = (isB ? p.N : p.M) - 8;
+    gcol = gcol < lim ? gcol : lim;  // columns past the edge re-read valid data; their products are never stored
+    src[j] = (isB ? p.b_hi : p.a_hi) + (long)(kbeg + k) * (isB ? p.ldb : p.lda) + gcol;
+  }
+  const long stepA = 64L * p.lda, stepB = 64L * p.ldb;
+  auto issue = [&](int kt, int stage) {
+#pragma unroll
+    for (int j = 0; j < UPW; ++j) {
+      const bool isB = (wave + 8 * j) >= A_UNITS;
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + kt * (isB ? stepB : stepA)),
+                                       (lds_ptr_t)(smem + stage * STAGE + (wave + 8 * j) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][NT];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read lane geometry: group g = lane>>4 owns k = 8g..8g+7 of the 32-deep MFMA step; inside the group
+  // lane 4q+pp addresses row q, columns 4pp..4pp+3 of the 4 x 16 block
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
+  const int hq = qq | ((g & 1) << 2);
+  const int a_k = (8 * g + qq) * A_ROWB + pp * 8;
+  const int b_k = A_UNITS * 1024 + (8 * g + qq) * B_ROWB + pp * 8;
+
+  issue(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 b[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const unsigned char* bp = st + b_k + kk * 32 * B_ROWB + (((wn * NT + j) ^ hq) << 5);
+        b[j] = tr_frag(bp, bp + 4 * B_ROWB);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned char* ap = st + a_k + kk * 32 * A_ROWB + (((wm * 8 + i) ^ hq) << 5);
+        const bf16x8 a = tr_frag(ap, ap + 4 * A_ROWB);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  float* out32 = p.out32 + (long)blockIdx.y * p.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = row0 + wm * 128 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n0 = col0 + wn * (BN / 4) + j * 16 + 4 * (lane >> 4);
+      if (n0 < p.N) epilogue_store4<VL_EPI_F32>(p, out32, m, n0, acc[i][j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // generic path
 // ---------------------------------------------------------------------------------------------------------------
 template <int NSPLIT, int EPI>
@@ -569,5 +682,50 @@ extern "C" int vl_debug_set(int key, int value) {
   if (key == 1) g_force_bn = value;
   else if (key == 2) g_force_generic = value;
   else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
+  return 0;
+}
+
+// dW[M,N] = A^T B with A [K, M] (lda), B [K, N] (ldb) row-major bf16 (the activations as they sit in HBM), K = the
+// B*S batch rows, split over `splits` workgroups per output tile (see vl_gemm_nt_splitk).  Needs K % 64 == 0,
+// M, N multiples of 8 and >= 16; otherwise returns -2 and the caller uses the transposing path.
+extern "C" int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N,
+                                 int64_t K, int64_t splits, float* ws, float* out32, void* stream) {
+  VL_CHECK_ARG(a && b && out32 && M > 0 && N > 0 && K > 0 && splits >= 1 && splits <= 64 && (splits == 1 || ws),
+               "vl_gemm_tn_splitk: bad arguments");
+  if ((K % 64) != 0 || (M & 7) || (N & 7) || M < 256 || N < 128 || (lda & 7) || (ldb & 7) || !aligned16(a) ||
+      !aligned16(b) || ((M * N) & 3) || !aligned16(out32) || !aligned16(ws))
+    return vl_set_error(-2, "vl_gemm_tn_splitk: shape not supported by the TN fast path");
+  GemmArgs g{};
+  g.a_hi = (const bf16_raw*)a; g.b_hi = (const bf16_raw*)b;
+  g.lda = lda; g.ldb = ldb; g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.ldc = N; g.vec = 1;
+  int64_t k_len = (K + splits - 1) / splits;
+  k_len = (k_len + 63) / 64 * 64;
+  const int eff = (int)((K + k_len - 1) / k_len);
+  g.k_len = (int)k_len;
+  g.out32 = eff == 1 ? out32 : ws;
+  g.slab_stride = eff == 1 ? 0 : M * N;
+  const int bn = (N % 256 == 0 || N > 1024) ? 256 : 128;
+  g.tiles_m = (int)((M + 255) / 256);
+  g.tiles_n = (int)((N + bn - 1) / bn);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds = 2 * (size_t)(64 * 512 + 64 * bn * 2);
+  hipError_t e = bn == 256 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_tn_kernel<256>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                           : hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_tn_kernel<128>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_tn_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  if (bn == 256)
+    hipLaunchKernelGGL((gemm2_tn_kernel<256>), dim3(g.tiles_m * g.tiles_n, eff), dim3(512), lds, s, g);
+  else
+    hipLaunchKernelGGL((gemm2_tn_kernel<128>), dim3(g.tiles_m * g.tiles_n, eff), dim3(512), lds, s, g);
+  VL_CHECK_LAUNCH("vl_gemm_tn_splitk");
+  if (eff > 1) {
+    const long n4 = (long)(M * N / 4);
+    long gr = (n4 + 255) / 256;
+    if (gr > 2048) gr = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gr), dim3(256), 0, s, ws, eff, n4, out32);
+    VL_CHECK_LAUNCH("vl_gemm_tn_splitk(reduce)");
+  }
   return 0;
 }

@@ -74,13 +74,15 @@ class PreparedWeight(object):
 def dw_gemm(dy16, x16, M, N, K):
     """dW[N,K] = dY[M,N]^T . X[M,K] (bf16 operands, fp32 out) as an NT GEMM over transposed copies."""
     dev = dy16.device
+    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+    if ops.gemm_tn_splitk(dy16, x16, N, K, M, dW):
+        return dW
     Mp = _ceil8(M)
     alloc = torch.zeros if Mp != M else torch.empty
     dyT = alloc(N, Mp, dtype=BF16, device=dev)
     xT = alloc(K, Mp, dtype=BF16, device=dev)
     ops.transpose_bf16(dy16, dyT, M, N)
     ops.transpose_bf16(x16, xT, M, K)
-    dW = torch.empty(N, K, dtype=torch.float32, device=dev)
     ops.gemm_nt_splitk(dyT, xT, N, K, Mp, dW)
     return dW
 

@@ -66,6 +66,25 @@ def gemm_nt_splitk(a_hi, b_hi, M, N, K, out32, splits=None):
                "vl_gemm_nt_splitk")
 
 
+def gemm_tn_splitk(a, b, M, N, K, out32, splits=None):
+    """out32[M,N] = A[K,M]^T . B[K,N] (row-major bf16 activations).  Returns False when the shape is outside the TN
+    fast path (the caller then transposes and uses gemm_nt_splitk)."""
+    L = _lib.lib()
+    if splits is None:
+        splits = L.vl_gemm_splitk_plan(M, N, K)
+    ws = None
+    if splits > 1:
+        ws = torch.empty(L.vl_gemm_splitk_ws_floats(M, N, splits), dtype=torch.float32, device=out32.device)
+    pa, lda = _pld(a)
+    pb, ldb = _pld(b)
+    assert out32.is_contiguous() and out32.shape[-1] == N
+    rc = L.vl_gemm_tn_splitk(pa, lda, pb, ldb, M, N, K, splits, _p(ws), _p(out32), _stream())
+    if rc == -2:
+        return False
+    _lib.check(rc, "vl_gemm_tn_splitk")
+    return True
+
+
 def attn_fwd(qkv32, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed):
     _lib.check(_lib.lib().vl_attn_fwd(_p(qkv32), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
                                       float(p_drop), int(seed), _stream()), "vl_attn_fwd")

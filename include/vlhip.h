@@ -58,6 +58,12 @@ int64_t vl_gemm_splitk_ws_floats(int64_t M, int64_t N, int64_t splits);
 int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float* ws, float* out32, void* stream);
 
+/* Same product straight from row-major activations: out32[M,N] = A^T B with A [K,M], B [K,N] (K = batch rows), using
+ * transposing LDS reads (ds_read_b64_tr_b16) instead of transposed HBM copies.  Returns -2 when the shape is outside
+ * the fast path (K % 64, M >= 256, N >= 128, M/N multiples of 8): use vl_transpose_bf16 + vl_gemm_nt_splitk then. */
+int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                      int64_t splits, float* ws, float* out32, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused V&L attention core over the single stream X = [text ; boxes]  (S = T + V <= 160, head dim 64).
  * Replaces encoders.py:255-341: four gated score blocks, two concatenated softmaxes, four dropouts, four P.V

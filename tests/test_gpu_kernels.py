@@ -84,6 +84,19 @@ def test_gemm_splitk(M, N, K):
     torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(K / 256))
 
 
+@pytest.mark.parametrize("M,N,K", [(768, 768, 14336), (2304, 768, 1024), (768, 3072, 2048), (3072, 768, 14336),
+                                   (264, 136, 128), (776, 1032, 256)])
+def test_gemm_tn_splitk(M, N, K):
+    """dW = A^T B straight from [K,M] / [K,N] row-major operands (transposing LDS reads)."""
+    a = _rand(K, M, seed=42).to(BF16)
+    b = _rand(K, N, seed=43).to(BF16)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    assert ops.gemm_tn_splitk(a, b, M, N, K, out)
+    ref = (a.double().t() @ b.double()).float()
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(K / 256))
+    assert not ops.gemm_tn_splitk(a[:, :64].contiguous(), b, 64, N, K, out[:64].contiguous())  # outside the fast path
+
+
 def test_gemm_epilogues():
     M, N, K = 384, 512, 256
     x, w, bias = _rand(M, K, seed=9), _rand(N, K, seed=10, scale=0.1), _rand(N, seed=11)
