@@ -30,6 +30,11 @@
 
 namespace {
 
+int g_force_bn = 0;       // tuning knobs (vl_debug_set): 0 = automatic
+int g_force_generic = 0;
+int g_wave_rows = 4;      // 2: 512-thread workgroups (8 waves), 4: 1024-thread workgroups (16 waves)
+int g_alias_rows = 0;     // timing experiment only: A rows wrap modulo this (makes the A operand cache resident)
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
@@ -40,6 +45,7 @@ struct GemmArgs {
   const float* bias; const float* resid; float* out32; long ldc;
   bf16_raw* out_hi; bf16_raw* out_lo; bf16_raw* aux16; long ld16;
   int tiles_m, tiles_n;
+  int alias_rows;               // debug / timing experiment (0 = off)
   int vec;                      // 1: leading dimensions / pointers allow the 16-byte (fp32) / 8-byte (bf16) epilogue
   int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
 };
@@ -132,11 +138,13 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <int NSPLIT, int EPI, int BN>
-__global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs p) {
-  constexpr int BM2 = 256, NT = BN / 64;                  // 16-wide n-tiles per wave (wave tile 128 x BN/4)
+template <int NSPLIT, int EPI, int BN, int WM>
+__global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
+  constexpr int BM2 = 256, NT = BN / 64;                  // 16-wide n-tiles per wave (wave tile 256/WM x BN/4)
+  constexpr int MT = 16 / WM;                              // 16-high m-tiles per wave
+  constexpr int NWAVES = WM * 4;
   constexpr int A_UNITS = BM2 / 8, UNITS = (BM2 + BN) / 8;  // 1-KiB DMA units (8 rows x 128 B) per stage
-  constexpr int UPW = UNITS / 8;                           // units per wave
+  constexpr int UPW = (UNITS + NWAVES - 1) / NWAVES;       // units per wave
   constexpr int STAGE = UNITS * 1024;
   constexpr int KSTEP = NSPLIT == 3 ? 32 : 64;             // k elements consumed per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -159,12 +167,14 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs p) {
   const bf16_raw* src[UPW];
 #pragma unroll
   for (int j = 0; j < UPW; ++j) {
-    const int u = wave + 8 * j;
+    const int u = wave + NWAVES * j;
     const bool isB = u >= A_UNITS;
     const int trow = (isB ? u - A_UNITS : u) * 8 + (lane >> 3);
+    if (u >= UNITS) { src[j] = p.a_hi; continue; }
     int grow = (isB ? col0 : row0) + trow;
     const int lim = (isB ? p.N : p.M) - 1;
     grow = grow < lim ? grow : lim;  // rows past the edge re-read the last row; their products are never stored
+    if (!isB && p.alias_rows) grow %= p.alias_rows;
     const int lc = (lane & 7) ^ ((trow >> 1) & 7);  // logical 16-B chunk that lands at physical position lane&7
     const bf16_raw* base;
     int koff;
@@ -180,22 +190,23 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs p) {
   auto issue = [&](int kt, int stage) {
 #pragma unroll
     for (int j = 0; j < UPW; ++j)
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + kt * KSTEP),
-                                       (lds_ptr_t)(smem + stage * STAGE + (wave + 8 * j) * 1024), 16, 0, 0);
+      if (wave + NWAVES * j < UNITS)
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + kt * KSTEP),
+                                         (lds_ptr_t)(smem + stage * STAGE + (wave + NWAVES * j) * 1024), 16, 0, 0);
   };
 
-  f32x4 acc[8][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fk = lane >> 4;
   // fragment byte offsets inside a stage (row-dependent swizzle folded in); chunk index is XORed per read
-  int a_off[8], a_sw[8], b_off[NT], b_sw[NT];
+  int a_off[MT], a_sw[MT], b_off[NT], b_sw[NT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = wm * 128 + i * 16 + frow;
+  for (int i = 0; i < MT; ++i) {
+    const int row = wm * (16 * MT) + i * 16 + frow;
     a_off[i] = row * 128;
     a_sw[i] = (row >> 1) & 7;
   }
@@ -219,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs p) {
         for (int j = 0; j < NT; ++j)
           b[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + (((kk * 4 + fk) ^ b_sw[j]) << 4));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < MT; ++i) {
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(st + a_off[i] + (((kk * 4 + fk) ^ a_sw[i]) << 4));
 #pragma unroll
           for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[i][j], 0, 0, 0);
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs p) {
         bl[j] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + (((4 + fk) ^ b_sw[j]) << 4));
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < MT; ++i) {
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(st + a_off[i] + ((fk ^ a_sw[i]) << 4));
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(st + a_off[i] + (((4 + fk) ^ a_sw[i]) << 4));
 #pragma unroll
@@ -250,8 +261,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_kernel(GemmArgs p) {
   // epilogue.  D^T layout: lane&15 -> m inside the 16-row tile, 4*(lane>>4) + reg -> n inside the 16-col tile
   float* out32 = p.out32 + (long)blockIdx.y * p.slab_stride;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = row0 + wm * 128 + i * 16 + (lane & 15);
+  for (int i = 0; i < MT; ++i) {
+    const int m = row0 + wm * (16 * MT) + i * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -279,11 +290,11 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0, const unsigne
 }
 
 template <int BN>
-__global__ __launch_bounds__(512, 2) void gemm2_tn_kernel(GemmArgs p) {
-  constexpr int BM2 = 256, NT = BN / 64;
+__global__ __launch_bounds__(1024, 4) void gemm2_tn_kernel(GemmArgs p) {
+  constexpr int BM2 = 256, NT = BN / 64, MT = 4, NWAVES = 16;
   constexpr int A_ROWB = BM2 * 2, B_ROWB = BN * 2;          // bytes per k-row of the A / B tile
   constexpr int A_UNITS = 64 * A_ROWB / 1024, B_UNITS = 64 * B_ROWB / 1024, UNITS = A_UNITS + B_UNITS;
-  constexpr int UPW = UNITS / 8, STAGE = UNITS * 1024;
+  constexpr int UPW = UNITS / NWAVES, STAGE = UNITS * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -302,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void gemm2_tn_kernel(GemmArgs p) {
   const bf16_raw* src[UPW];
 #pragma unroll
   for (int j = 0; j < UPW; ++j) {
-    const int u = wave + 8 * j;
+    const int u = wave + NWAVES * j;
     const bool isB = u >= A_UNITS;
     const int rowb = isB ? B_ROWB : A_ROWB;
     const int cpr = rowb / 16;                         // 16-byte chunks per k-row (32 or 16)
@@ -318,15 +329,15 @@ __global__ __launch_bounds__(512, 2) void gemm2_tn_kernel(GemmArgs p) {
   auto issue = [&](int kt, int stage) {
 #pragma unroll
     for (int j = 0; j < UPW; ++j) {
-      const bool isB = (wave + 8 * j) >= A_UNITS;
+      const bool isB = (wave + NWAVES * j) >= A_UNITS;
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + kt * (isB ? stepB : stepA)),
-                                       (lds_ptr_t)(smem + stage * STAGE + (wave + 8 * j) * 1024), 16, 0, 0);
+                                       (lds_ptr_t)(smem + stage * STAGE + (wave + NWAVES * j) * 1024), 16, 0, 0);
     }
   };
 
-  f32x4 acc[8][NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -351,8 +362,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_tn_kernel(GemmArgs p) {
         b[j] = tr_frag(bp, bp + 4 * B_ROWB);
       }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const unsigned char* ap = st + a_k + kk * 32 * A_ROWB + (((wm * 8 + i) ^ hq) << 5);
+      for (int i = 0; i < MT; ++i) {
+        const unsigned char* ap = st + a_k + kk * 32 * A_ROWB + (((wm * MT + i) ^ hq) << 5);
         const bf16x8 a = tr_frag(ap, ap + 4 * A_ROWB);
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a, acc[i][j], 0, 0, 0);
@@ -363,8 +374,8 @@ __global__ __launch_bounds__(512, 2) void gemm2_tn_kernel(GemmArgs p) {
 
   float* out32 = p.out32 + (long)blockIdx.y * p.slab_stride;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = row0 + wm * 128 + i * 16 + (lane & 15);
+  for (int i = 0; i < MT; ++i) {
+    const int m = row0 + wm * (16 * MT) + i * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
@@ -512,25 +523,29 @@ int launch(const GemmArgs& a, hipStream_t stream, int splits = 1) {
   return 0;
 }
 
-template <int NSPLIT, int EPI, int BN>
-int launch2(GemmArgs a, hipStream_t stream, int splits) {
+template <int NSPLIT, int EPI, int BN, int WM>
+int launch2w(GemmArgs a, hipStream_t stream, int splits) {
   const size_t lds = 2 * ((256 + BN) / 8) * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, BN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<NSPLIT, EPI, BN, WM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, BN>), dim3(a.tiles_m * a.tiles_n, splits), dim3(512), lds, stream, a);
+  a.alias_rows = g_alias_rows;
+  hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, BN, WM>), dim3(a.tiles_m * a.tiles_n, splits), dim3(WM * 256), lds,
+                     stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt(fast)");
   return 0;
 }
+template <int NSPLIT, int EPI, int BN>
+int launch2(const GemmArgs& a, hipStream_t stream, int splits) {
+  return g_wave_rows == 4 ? launch2w<NSPLIT, EPI, BN, 4>(a, stream, splits) : launch2w<NSPLIT, EPI, BN, 2>(a, stream, splits);
+}
 
-int g_force_bn = 0;       // tuning knobs (vl_debug_set): 0 = automatic
-int g_force_generic = 0;
 
 // BN for the fast path: fewest "rounds x tile width" over the 256 CUs (one 512-thread workgroup per CU)
 inline int pick_bn(int64_t M, int64_t N, int splits) {
@@ -681,6 +696,8 @@ extern "C" int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi
 extern "C" int vl_debug_set(int key, int value) {
   if (key == 1) g_force_bn = value;
   else if (key == 2) g_force_generic = value;
+  else if (key == 3) g_alias_rows = value;
+  else if (key == 4) g_wave_rows = value;
   else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
   return 0;
 }
@@ -716,9 +733,9 @@ extern "C" int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int6
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_tn_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e));
   if (bn == 256)
-    hipLaunchKernelGGL((gemm2_tn_kernel<256>), dim3(g.tiles_m * g.tiles_n, eff), dim3(512), lds, s, g);
+    hipLaunchKernelGGL((gemm2_tn_kernel<256>), dim3(g.tiles_m * g.tiles_n, eff), dim3(1024), lds, s, g);
   else
-    hipLaunchKernelGGL((gemm2_tn_kernel<128>), dim3(g.tiles_m * g.tiles_n, eff), dim3(512), lds, s, g);
+    hipLaunchKernelGGL((gemm2_tn_kernel<128>), dim3(g.tiles_m * g.tiles_n, eff), dim3(1024), lds, s, g);
   VL_CHECK_LAUNCH("vl_gemm_tn_splitk");
   if (eff > 1) {
     const long n4 = (long)(M * N / 4);

@@ -31,7 +31,7 @@ def main():
     shapes = [("qkv   fwd", 14336, 2304, 768), ("oproj fwd", 14336, 768, 768), ("ffn1  fwd", 14336, 3072, 768),
               ("ffn2  fwd", 14336, 768, 3072), ("small-A  ", 2048, 768, 3072)]
     variants = [("generic", dict(g=1, bn=0)), ("bn256", dict(g=0, bn=256)), ("bn192", dict(g=0, bn=192)),
-                ("bn128", dict(g=0, bn=128))]
+                ("bn256-w16", dict(g=0, bn=256, wr=4)), ("bn192-w16", dict(g=0, bn=192, wr=4))]
     for passes in (1, 3):
         print("== passes %d ==" % passes)
         for name, M, N, K in shapes:
@@ -44,11 +44,15 @@ def main():
             for vname, v in variants:
                 L.vl_debug_set(2, v["g"])
                 L.vl_debug_set(1, v["bn"])
+                L.vl_debug_set(3, v.get("alias", 0))
+                L.vl_debug_set(4, v.get("wr", 2))
                 us = bench(lambda: ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, out32=out))
                 row.append("%s %7.1f us %6.0f TF" % (vname, us, 2.0 * M * N * K / us / 1e6))
             print("%s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
     L.vl_debug_set(1, 0)
     L.vl_debug_set(2, 0)
+    L.vl_debug_set(3, 0)
+    L.vl_debug_set(4, 2)
 
 
 if __name__ == "__main__":
