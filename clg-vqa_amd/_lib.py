@@ -32,6 +32,7 @@ _SIGS = {
                           c_float, c_uint64, P]),
     "vl_mask_mul": (c_int, [P, P, P, c_int64, P]),
     "vl_weight_prep": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
+    "vl_weight_prep_multi": (c_int, [P, c_int64, c_int64, P]),
     "vl_split_f32": (c_int, [P, P, P, c_int64, P]),
     "vl_transpose_bf16": (c_int, [P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "vl_colsum_ws_floats": (c_int64, [c_int64, c_int64]),

@@ -51,11 +51,9 @@ __global__ void split_kernel(const float* __restrict__ x, bf16_raw* __restrict__
 }
 
 // ---- weight prep: W[N,K] (*mask) -> w_hi, w_lo [N,K] (ld = ldw) and wt_hi [K,N] (ld = ldt) -------------------
-__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ mask,
-                                                          bf16_raw* w_hi, bf16_raw* w_lo, bf16_raw* wt_hi, int N,
-                                                          int K, long ldw, long ldt) {
-  __shared__ bf16_raw tile[64][66];
-  const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+__device__ __forceinline__ void weight_prep_tile(const float* __restrict__ w, const float* __restrict__ mask,
+                                                 bf16_raw* w_hi, bf16_raw* w_lo, bf16_raw* wt_hi, int N, int K,
+                                                 long ldw, long ldt, int n0, int k0, bf16_raw (*tile)[66]) {
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int rr = ty; rr < 64; rr += 4) {
     const int n = n0 + rr, k = k0 + tx;
@@ -76,6 +74,26 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restric
     const int k = k0 + rr, n = n0 + tx;
     if (k < K && n < N) wt_hi[(long)k * ldt + n] = tile[tx][rr];
   }
+}
+__global__ __launch_bounds__(256) void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ mask,
+                                                          bf16_raw* w_hi, bf16_raw* w_lo, bf16_raw* wt_hi, int N,
+                                                          int K, long ldw, long ldt) {
+  __shared__ bf16_raw tile[64][66];
+  weight_prep_tile(w, mask, w_hi, w_lo, wt_hi, N, K, ldw, ldt, blockIdx.y * 64, blockIdx.x * 64, tile);
+}
+// all Linear weights of the model in ONE launch: a device table of 10 x int64 per weight
+// [w32, mask32, w_hi, w_lo, wt_hi, N, K, ldw, ldt, first_tile]; blockIdx.x is a global 64x64-tile index.
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const int64_t* __restrict__ tab, int nd) {
+  __shared__ bf16_raw tile[64][66];
+  int i = 0;
+  while (i + 1 < nd && tab[(i + 1) * 10 + 9] <= (int64_t)blockIdx.x) ++i;
+  const int64_t* d = tab + i * 10;
+  const int N = (int)d[5], K = (int)d[6];
+  const int t = (int)(blockIdx.x - d[9]);
+  const int tiles_k = (K + 63) / 64;
+  weight_prep_tile(reinterpret_cast<const float*>(d[0]), reinterpret_cast<const float*>(d[1]),
+                   reinterpret_cast<bf16_raw*>(d[2]), reinterpret_cast<bf16_raw*>(d[3]),
+                   reinterpret_cast<bf16_raw*>(d[4]), N, K, d[7], d[8], (t / tiles_k) * 64, (t % tiles_k) * 64, tile);
 }
 
 // ---- bf16 transpose [M,N] -> [N,M] ------------------------------------------------------------------------------
@@ -336,6 +354,14 @@ extern "C" int vl_weight_prep(const float* w32, const float* mask32, void* w_hi,
                      (hipStream_t)stream, w32, mask32, (bf16_raw*)w_hi, (bf16_raw*)w_lo, (bf16_raw*)wt_hi, (int)N,
                      (int)K, (long)ldw, (long)ldt);
   VL_CHECK_LAUNCH("vl_weight_prep");
+  return 0;
+}
+
+extern "C" int vl_weight_prep_multi(const int64_t* table_dev, int64_t ndesc, int64_t total_tiles, void* stream) {
+  VL_CHECK_ARG(table_dev && ndesc > 0 && total_tiles > 0 && total_tiles < (1LL << 31), "vl_weight_prep_multi: bad arguments");
+  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, table_dev,
+                     (int)ndesc);
+  VL_CHECK_LAUNCH("vl_weight_prep_multi");
   return 0;
 }
 

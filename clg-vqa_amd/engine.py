@@ -55,6 +55,24 @@ class PreparedWeight(object):
                       l.bias.data_ptr(), l.bias._version))
         return tuple(k)
 
+    def descriptors(self):
+        """Rows of the vl_weight_prep_multi table (one per source Linear)."""
+        rows, r = [], 0
+        for l in self.linears:
+            w, m = linear_params(l)
+            n = l.out_features
+            hi, lo = self.hi[r:r + n], self.lo[r:r + n]
+            t = None if self.t_hi is None else self.t_hi[:, r:r + n]
+            rows.append([w.data_ptr(), 0 if m is None else m.data_ptr(), hi.data_ptr(), lo.data_ptr(),
+                         0 if t is None else t.data_ptr(), n, self.K, self.K, 0 if t is None else self.Np])
+            r += n
+        return rows
+
+    def refresh_bias(self):
+        self.bias = (self.linears[0].bias.detach() if len(self.linears) == 1
+                     else torch.cat([l.bias.detach() for l in self.linears]))
+        self.key = self._key()
+
     def refresh(self, force=False):
         key = self._key()
         if not force and key == self.key:
@@ -105,6 +123,10 @@ class UC2Engine(object):
             raise ValueError("clg_vqa_amd: hidden size must be a multiple of 256 for the native LayerNorm")
         self._prepared = None
         self._dirty = True
+        # optional: a zero-initialised, optimizer-owned fp32 buffer the word-embedding gradient is scatter-added
+        # into directly (FusedAdamW installs a view of its flat gradient arena; the arena is re-zeroed by the
+        # optimizer kernel).  Saves the 768 MB zero-fill and the 768 MB copy per step of the dense path.
+        self.word_grad_sink = None
         self.base_seed = 0x5EED
         self.calls = 0
 
@@ -151,11 +173,22 @@ class UC2Engine(object):
                                   layers=layers)
             self._dirty = True
         pw = self._prepared
-        force = self._dirty
-        pw["img"].refresh(force)
-        for lw in pw["layers"]:
-            for k in ("qkv", "o", "w1", "w2"):
-                lw[k].refresh(force)
+        all_pw = [pw["img"]] + [lw[k] for lw in pw["layers"] for k in ("qkv", "o", "w1", "w2")]
+        if self._dirty or any(p._key() != p.key for p in all_pw):
+            ptrs = tuple(r[0] for p in all_pw for r in p.descriptors())
+            if pw.get("table_ptrs") != ptrs or pw.get("table_masks") != tuple(r[1] for p in all_pw for r in p.descriptors()):
+                rows, tile0 = [], 0
+                for p in all_pw:
+                    for r in p.descriptors():
+                        rows.append(r + [tile0])
+                        tile0 += ((r[5] + 63) // 64) * ((r[6] + 63) // 64)
+                pw["table"] = torch.tensor(rows, dtype=torch.int64).to(device)
+                pw["table_ptrs"] = ptrs
+                pw["table_masks"] = tuple(r[1] for r in rows)
+                pw["table_tiles"] = tile0
+            ops.weight_prep_multi(pw["table"], pw["table"].shape[0], pw["table_tiles"])  # one launch per step
+            for p in all_pw:
+                p.refresh_bias()
         self._dirty = False
         return pw
 
@@ -316,7 +349,9 @@ class UC2Engine(object):
 
         # --- embeddings backward (dy = dL/dX0 [M,H]) ---
         type_w = emb.new_token_type_embeddings.weight
-        dword = torch.zeros_like(emb.word_embeddings.weight)
+        sink = self.word_grad_sink
+        use_sink = sink is not None and sink.shape == emb.word_embeddings.weight.shape and sink.device == dev
+        dword = sink if use_sink else torch.zeros_like(emb.word_embeddings.weight)
         dpos = torch.zeros_like(emb.position_embeddings.weight)
         dtype_ = torch.zeros_like(type_w)
         # box rows
@@ -339,7 +374,7 @@ class UC2Engine(object):
                    db_e, None, ws, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
         ops.embed_text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id))
         dtype_[1] += dtype1  # image_token_type_embeddings is new_token_type_embeddings (embeddings.py:628)
-        grads = [dword, dpos, dtype_, dg_e, db_e, dWimg, dbias_img, dWl, dbl, dg_i, db_i, dg_l, db_l, dg_v, db_v]
+        grads = [None if use_sink else dword, dpos, dtype_, dg_e, db_e, dWimg, dbias_img, dWl, dbl, dg_i, db_i, dg_l, db_l, dg_v, db_v]
         for lg in layer_grads:
             grads += lg
         return grads

@@ -132,6 +132,10 @@ def weight_prep(w32, mask32, w_hi, w_lo, wt_hi):
                "vl_weight_prep")
 
 
+def weight_prep_multi(table_dev, ndesc, total_tiles):
+    _lib.check(_lib.lib().vl_weight_prep_multi(_p(table_dev), ndesc, total_tiles, _stream()), "vl_weight_prep_multi")
+
+
 def split_f32(x32, hi, lo=None):
     _lib.check(_lib.lib().vl_split_f32(_p(x32), _p(hi), _p(lo), x32.numel(), _stream()), "vl_split_f32")
 

@@ -132,6 +132,12 @@ class FusedAdamW(object):
         self._scale = torch.zeros(1, dtype=torch.float32, device=device)
         if hasattr(model, "mark_weights_dirty"):
             model.mark_weights_dirty()
+        eng = getattr(model, "engine", None)
+        if eng is not None:  # scatter the word-embedding gradient straight into the (zeroed) arena
+            we = model.bert.embeddings.word_embeddings.weight
+            for (_, p, _, _), gv in zip(self.groups, self.arena.grad_views):
+                if p is we:
+                    eng.word_grad_sink = gv
 
     def lr_mult(self):
         if self.t_total is None:

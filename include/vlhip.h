@@ -121,6 +121,11 @@ int vl_mask_mul(const float* a, const float* m, float* out, int64_t n, void* str
 int vl_weight_prep(const float* w32, const float* mask32, void* w_hi, void* w_lo, void* wt_hi, int64_t N,
                    int64_t K, int64_t ldw, int64_t ldt, void* stream);
 
+/* Batched form: ONE launch for every Linear weight of the model.  table_dev: device array of ndesc x 10 int64
+ * [w32, mask32 (0 = none), w_hi, w_lo, wt_hi (0 = none), N, K, ldw, ldt, first_tile] with first_tile = running sum of
+ * ceil(N/64)*ceil(K/64); total_tiles = the grand total. */
+int vl_weight_prep_multi(const int64_t* table_dev, int64_t ndesc, int64_t total_tiles, void* stream);
+
 /* Elementwise / layout helpers. */
 int vl_split_f32(const float* x32, void* hi, void* lo, int64_t n, void* stream); /* lo may be NULL (plain cast) */
 int vl_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t ld_out, void* stream);
