@@ -70,6 +70,25 @@ class GemmTimer(object):
         return out
 
 
+def pmc_traffic_per_launch(prefix="gemm2_kernel<3,"):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_summary.json,
+    produced by tools/profile_summary.py from separate rocprofv3 --pmc passes; FETCH_SIZE doubled for gfx950)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
+    if not files:
+        return None
+    try:
+        pm = json.load(open(files[-1])).get("pmc", {})
+        tot, n = 0.0, 0
+        for k, v in pm.items():
+            if k.startswith(prefix):
+                tot += (v["hbm_read_MB_per_launch"] + v["hbm_write_MB_per_launch"]) * 1e6 * v["launches"]
+                n += v["launches"]
+        return round(tot / n) if n else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(seconds_budget=25.0):
     """Oracle fwd+bwd on the host cores: UC2 full config, micro-batch 32."""
     from helpers import TASK_CFG
@@ -198,13 +217,13 @@ def main():
         roof = None
         if 3 in gs:
             ach = gs[3]["flops"] / (gs[3]["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="gemm_nt_kernel<3,*> (forward, 3-pass split bf16)", achieved=round(ach, 2),
+            roof = dict(bound="mfma", kernel="gemm2_kernel<3,*> (forward GEMMs, 3-pass split bf16 MFMA)", achieved=round(ach, 2),
                         peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                        traffic=None, mfma_passes=3, mfma_issue_frac=round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        traffic=pmc_traffic_per_launch(), algorithmic_bytes_per_launch=None, mfma_passes=3, mfma_issue_frac=round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         launches=gs[3]["launches"], avg_launch_us=round(1e3 * gs[3]["ms"] / gs[3]["launches"], 2))
             if 1 in gs:
                 a1 = gs[1]["flops"] / (gs[1]["ms"] * 1e-3) / 1e12
-                roof["backward_gemm"] = dict(kernel="gemm_nt_kernel<1,*> (backward, bf16)", achieved=round(a1, 2),
+                roof["backward_gemm"] = dict(kernel="gemm2_kernel<1,*> (backward dX GEMMs, bf16 MFMA)", achieved=round(a1, 2),
                                              frac=round(a1 / MFMA_BF16_PEAK_TFLOPS, 4), launches=gs[1]["launches"],
                                              avg_launch_us=round(1e3 * gs[1]["ms"] / gs[1]["launches"], 2))
         line = {
