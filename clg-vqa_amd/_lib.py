@@ -32,6 +32,8 @@ _SIGS = {
                           c_float, c_uint64, P]),
     "vl_mask_mul": (c_int, [P, P, P, c_int64, P]),
     "vl_weight_prep": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
+    "vl_imp_ws_bytes": (c_int64, [c_int64]),
+    "vl_imp_select": (c_int, [P, P, P, c_int64, c_int64, P, P]),
     "vl_weight_prep_multi": (c_int, [P, c_int64, c_int64, P]),
     "vl_split_f32": (c_int, [P, P, P, c_int64, P]),
     "vl_transpose_bf16": (c_int, [P, P, c_int64, c_int64, c_int64, c_int64, P]),

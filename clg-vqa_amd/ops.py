@@ -132,6 +132,15 @@ def weight_prep(w32, mask32, w_hi, w_lo, wt_hi):
                "vl_weight_prep")
 
 
+def imp_select(w_flat, mask_flat, new_mask_flat, k):
+    """One IMP round on the flat concatenation: the k smallest |w| with mask == 1 get mask 0."""
+    n = w_flat.numel()
+    ws = torch.empty(_lib.lib().vl_imp_ws_bytes(n), dtype=torch.uint8, device=w_flat.device)
+    _lib.check(_lib.lib().vl_imp_select(_p(w_flat), _p(mask_flat), _p(new_mask_flat), n, int(k), _p(ws), _stream()),
+               "vl_imp_select")
+    return new_mask_flat
+
+
 def weight_prep_multi(table_dev, ndesc, total_tiles):
     _lib.check(_lib.lib().vl_weight_prep_multi(_p(table_dev), ndesc, total_tiles, _stream()), "vl_weight_prep_multi")
 

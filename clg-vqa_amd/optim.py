@@ -139,6 +139,21 @@ class FusedAdamW(object):
                 if p is we:
                     eng.word_grad_sink = gv
 
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "opt_step": self.opt_step,
+                "sched_step": self.sched_step, "names": [g[0] for g in self.groups]}
+
+    def load_state_dict(self, sd):
+        assert sd["names"] == [g[0] for g in self.groups], "optimizer state belongs to a different parameter list"
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.opt_step, self.sched_step = int(sd["opt_step"]), int(sd["sched_step"])
+
+    def zero_grad(self):
+        self.arena.grad.zero_()
+        for _, p, _, _ in self.groups:
+            p.grad = None
+
     def lr_mult(self):
         if self.t_total is None:
             return 1.0

@@ -121,6 +121,14 @@ int vl_mask_mul(const float* a, const float* m, float* out, int64_t n, void* str
 int vl_weight_prep(const float* w32, const float* mask32, void* w_hi, void* w_lo, void* wt_hi, int64_t N,
                    int64_t K, int64_t ldw, int64_t ldt, void* stream);
 
+/* One round of global magnitude pruning (IMP): new_mask = mask with the k smallest |w| among entries with mask == 1
+ * set to 0 (w, mask, new_mask: n fp32, the flat concatenation of the prunable weights in named_modules() order;
+ * mask holds {0,1}).  Replaces prune.global_unstructured(L1Unstructured, amount) as called at
+ * train_task_prunning.py:80-84 (k = round(amount * n_remaining), torch prune.py:514-534).  Exact radix select on the
+ * fp32 bits; threshold ties are pruned lowest-flat-index-first.  ws >= vl_imp_ws_bytes(n) bytes.  No host sync. */
+int64_t vl_imp_ws_bytes(int64_t n);
+int vl_imp_select(const float* w, const float* mask, float* new_mask, int64_t n, int64_t k, void* ws, void* stream);
+
 /* Batched form: ONE launch for every Linear weight of the model.  table_dev: device array of ndesc x 10 int64
  * [w32, mask32 (0 = none), w_hi, w_lo, wt_hi (0 = none), N, K, ldw, ldt, first_tile] with first_tile = running sum of
  * ceil(N/64)*ceil(K/64); total_tiles = the grand total. */
