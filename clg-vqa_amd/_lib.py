@@ -25,11 +25,11 @@ _SIGS = {
     "vl_gemm_tn_splitk": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P]),
     "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
-    "vl_ln_fwd": (c_int, [P, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64,
-                          c_float, c_float, c_uint64, P]),
+    "vl_ln_fwd": (c_int, [P, P, P, c_int64, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64,
+                          c_int64, c_float, c_float, c_uint64, P]),
     "vl_ln_bwd_ws_floats": (c_int64, [c_int64, c_int64]),
-    "vl_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float,
-                          c_float, c_uint64, P]),
+    "vl_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64,
+                          c_float, c_float, c_uint64, P]),
     "vl_mask_mul": (c_int, [P, P, P, c_int64, P]),
     "vl_weight_prep": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "vl_imp_ws_bytes": (c_int64, [c_int64]),
@@ -42,6 +42,8 @@ _SIGS = {
     "vl_addmask": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_embed_text_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "vl_embed_text_bwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
+    "vl_embed_gather_fwd": (c_int, [P, P, P, c_int64, c_int64, P]),
+    "vl_embed_scatter_add": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_loc_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_loc_linear_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_adamw": (c_int, [P, P, P, P, c_int64, P, P, P, c_int64, c_float, c_float, c_float, c_int64, c_int, c_float,

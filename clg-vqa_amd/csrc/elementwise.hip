@@ -220,6 +220,27 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const int64_t* __re
   }
 }
 
+// ---- plain row gather / scatter-add (M3P text embedding: tensor = embeddings(x), m3p_transformer.py:908) -------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tab,
+                                                          float* __restrict__ out, long R, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const float* src = tab + ids[r] * (long)H;
+  for (int c = lane * 4; c < H; c += 256)
+    *reinterpret_cast<float4*>(out + r * H + c) = *reinterpret_cast<const float4*>(src + c);
+}
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dz,
+                                                           float* dtab, long R, int H, int64_t pad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long r = (long)blockIdx.x * 4 + wave;
+  if (r >= R) return;
+  const int64_t id = ids[r];
+  if (id == pad) return;  // nn.Embedding(padding_idx): the pad row receives no gradient
+  float* dst = dtab + id * (long)H;
+  for (int c = lane; c < H; c += 64) atomicAdd(dst + c, dz[r * H + c]);
+}
+
 // ---- box-location projection (embeddings.py:661: Linear(num_locs -> H)) ---------------------------------------
 __global__ void loc_fwd_kernel(const float* __restrict__ loc, const float* __restrict__ w, const float* __restrict__ b,
                                float* __restrict__ y, long R, int L, int H) {
@@ -421,6 +442,23 @@ extern "C" int vl_embed_text_bwd(const int64_t* ids, const int64_t* seg, const f
   hipLaunchKernelGGL(embed_text_bwd_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
                      seg, dz32, dword, dpos, dtype, (int)B, (int)T, (int)H, pad_id);
   VL_CHECK_LAUNCH("vl_embed_text_bwd");
+  return 0;
+}
+
+extern "C" int vl_embed_gather_fwd(const int64_t* ids, const float* table, float* out32, int64_t R, int64_t H,
+                                   void* stream) {
+  VL_CHECK_ARG(ids && table && out32 && R > 0 && H > 0 && H % 4 == 0, "vl_embed_gather_fwd: bad arguments");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids, table,
+                     out32, (long)R, (int)H);
+  VL_CHECK_LAUNCH("vl_embed_gather_fwd");
+  return 0;
+}
+extern "C" int vl_embed_scatter_add(const int64_t* ids, const float* dz32, float* dtable, int64_t R, int64_t H,
+                                    int64_t pad_id, void* stream) {
+  VL_CHECK_ARG(ids && dz32 && dtable && R > 0 && H > 0, "vl_embed_scatter_add: bad arguments");
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids, dz32,
+                     dtable, (long)R, (int)H, pad_id);
+  VL_CHECK_LAUNCH("vl_embed_scatter_add");
   return 0;
 }
 

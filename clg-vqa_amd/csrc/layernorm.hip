@@ -20,7 +20,8 @@ namespace {
 constexpr uint64_t POST_SALT = 0x5bd1e9955bd1e995ull;
 
 struct LnArgs {
-  float* y; const float* resid; const float* addvec; const float* gamma; const float* beta; float eps;
+  float* y; const float* resid; const float* addvec; long addvec_rows; const float* row_pre; const float* row_post;
+  const float* gamma; const float* beta; float eps;
   float* out32; bf16_raw* out_hi; bf16_raw* out_lo; float* mean; float* rstd;
   long M; int H; long group, out_stride, out_off;
   float p_pre, inv_pre, p_post, inv_post; uint64_t seed;
@@ -55,10 +56,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
       if (p.addvec) {
-        const float4 q = *reinterpret_cast<const float4*>(p.addvec + c);
+        const float4 q = *reinterpret_cast<const float4*>(p.addvec + (r % p.addvec_rows) * p.H + c);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
-      if (p.p_pre > 0.f || p.resid || p.addvec) *reinterpret_cast<float4*>(p.y + e) = v;  // z saved in place
+      if (p.row_pre) {
+        const float rp = p.row_pre[r];
+        v.x *= rp; v.y *= rp; v.z *= rp; v.w *= rp;
+      }
+      if (p.p_pre > 0.f || p.resid || p.addvec || p.row_pre) *reinterpret_cast<float4*>(p.y + e) = v;  // z saved in place
       z[i] = v;
       s += (v.x + v.y) + (v.z + v.w);
     }
@@ -88,6 +93,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
         o.y *= vl_dropout_scale(p.seed ^ POST_SALT, e + 1, p.p_post, p.inv_post);
         o.z *= vl_dropout_scale(p.seed ^ POST_SALT, e + 2, p.p_post, p.inv_post);
         o.w *= vl_dropout_scale(p.seed ^ POST_SALT, e + 3, p.p_post, p.inv_post);
+      }
+      if (p.row_post) {
+        const float rq = p.row_post[r];
+        o.x *= rq; o.y *= rq; o.z *= rq; o.w *= rq;
       }
       const long eo = orow * p.H + c;
       if (p.out32) *reinterpret_cast<float4*>(p.out32 + eo) = o;
@@ -126,6 +135,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
         d.z *= vl_dropout_scale(p.seed ^ POST_SALT, e + 2, p.p_post, p.inv_post);
         d.w *= vl_dropout_scale(p.seed ^ POST_SALT, e + 3, p.p_post, p.inv_post);
       }
+      if (p.row_post) {
+        const float rq = p.row_post[r];
+        d.x *= rq; d.y *= rq; d.z *= rq; d.w *= rq;
+      }
       const float4 zz = *reinterpret_cast<const float4*>(p.z + e);
       const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
       float4 x;
@@ -147,6 +160,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
       dz.y = (dy[i].y - c1 - xh[i].y * c2) * rs;
       dz.z = (dy[i].z - c1 - xh[i].z * c2) * rs;
       dz.w = (dy[i].w - c1 - xh[i].w * c2) * rs;
+      if (p.row_pre) {
+        const float rp = p.row_pre[r];
+        dz.x *= rp; dz.y *= rp; dz.z *= rp; dz.w *= rp;
+      }
       if (p.dz) *reinterpret_cast<float4*>(p.dz + e) = dz;
       float4 dp = dz;
       if (p.p_pre > 0.f) {
@@ -233,14 +250,16 @@ int check_shape(const char* fn, int64_t M, int64_t H, int64_t group, float p_pre
 
 }  // namespace
 
-extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, const float* gamma,
-                         const float* beta, float eps, float* out32, void* out_hi, void* out_lo, float* mean,
+extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, int64_t addvec_rows,
+                         const float* row_pre, const float* row_post, const float* gamma, const float* beta, float eps, float* out32, void* out_hi, void* out_lo, float* mean,
                          float* rstd, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
                          float p_pre, float p_post, uint64_t seed, void* stream) {
   if (int rc = check_shape("vl_ln_fwd", M, H, group, p_pre, p_post)) return rc;
   VL_CHECK_ARG(y32_z32 && gamma && beta && mean && rstd && (out32 || out_hi), "vl_ln_fwd: null pointer");
   LnArgs a{};
-  a.y = y32_z32; a.resid = resid32; a.addvec = addvec; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  VL_CHECK_ARG(!addvec || addvec_rows >= 1, "vl_ln_fwd: addvec_rows must be >= 1");
+  a.y = y32_z32; a.resid = resid32; a.addvec = addvec; a.addvec_rows = addvec_rows; a.row_pre = row_pre;
+  a.row_post = row_post; a.gamma = gamma; a.beta = beta; a.eps = eps;
   a.out32 = out32; a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.mean = mean; a.rstd = rstd;
   a.M = M; a.H = (int)H; a.group = group; a.out_stride = out_stride; a.out_off = out_off;
   a.p_pre = p_pre; a.inv_pre = 1.f / (1.f - p_pre); a.p_post = p_post; a.inv_post = 1.f / (1.f - p_post);
@@ -259,13 +278,14 @@ extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addv
 extern "C" int64_t vl_ln_bwd_ws_floats(int64_t M, int64_t H) { return (int64_t)nblk_for(M) * 3 * H; }
 
 extern "C" int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd,
-                         const float* gamma, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta,
+                         const float* gamma, const float* row_pre, const float* row_post, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta,
                          float* dbias, float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride,
                          int64_t out_off, float p_pre, float p_post, uint64_t seed, void* stream) {
   if (int rc = check_shape("vl_ln_bwd", M, H, group, p_pre, p_post)) return rc;
   VL_CHECK_ARG(dy32 && z32 && mean && rstd && gamma && partial_ws, "vl_ln_bwd: null pointer");
   LnArgs a{};
   a.dy = dy32; a.z = z32; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.gamma = gamma;
+  a.row_pre = row_pre; a.row_post = row_post;
   a.dz = dz32; a.dpre16 = (bf16_raw*)dpre16; a.dpre32 = dpre32; a.ws = partial_ws; a.nblk = nblk_for(M);
   a.M = M; a.H = (int)H; a.group = group; a.out_stride = out_stride; a.out_off = out_off;
   a.p_pre = p_pre; a.inv_pre = 1.f / (1.f - p_pre); a.p_post = p_post; a.inv_post = 1.f / (1.f - p_post);

@@ -105,21 +105,122 @@ def dw_gemm(dy16, x16, M, N, K):
     return dW
 
 
-class UC2Engine(object):
-    """Binds a ``BertForVLTasks`` module tree (reference parameter names) to the native kernels."""
+class LayerSpec(object):
+    """Leaf modules of one post-LN transformer layer (UC2: attention sub-layer 2l + feed-forward sub-layer 2l+1;
+    M3P: attentions[l] / layer_norm1[l] / ffns[l] / layer_norm2[l])."""
 
-    def __init__(self, model):
-        self.model = model
-        cfg = model.config
-        self.H = cfg.hidden_size
-        self.nh = cfg.num_attention_heads
-        self.I = cfg.intermediate_size
-        self.eps = cfg.layer_norm_eps
-        self.n_layers = len(model.bert.encoder.layer) // 2
-        if self.H % self.nh != 0 or self.H // self.nh != 64:
-            raise ValueError("clg_vqa_amd: the native attention kernel needs head dim 64 (hidden %d / heads %d)"
-                             % (self.H, self.nh))
-        if self.H % 256 != 0:
+    def __init__(self, q, k, v, o, ln1, w1, w2, ln2):
+        self.q, self.k, self.v, self.o, self.ln1, self.w1, self.w2, self.ln2 = q, k, v, o, ln1, w1, w2, ln2
+
+    def params(self):
+        ps = []
+        for lin in (self.q, self.k, self.v, self.o):
+            ps += [linear_params(lin)[0], lin.bias]
+        ps += [self.ln1.weight, self.ln1.bias]
+        for lin in (self.w1, self.w2):
+            ps += [linear_params(lin)[0], lin.bias]
+        ps += [self.ln2.weight, self.ln2.bias]
+        return ps
+
+
+def _masked(dw, lin):
+    m = linear_params(lin)[1]
+    if m is not None:  # SFT: grad(weight_orig) = grad(weight) (*) mask  (train_task_sft.py:128-132 autograd)
+        ops.mask_mul(dw, m, dw)
+    return dw
+
+
+class LayerStack(object):
+    """N x { QKV GEMM -> fused attention -> out-proj GEMM -> dropout+residual+LN -> FFN1 GEMM (+GELU) -> FFN2 GEMM ->
+    dropout+residual+LN [-> * row mask] } on the single [B*S, H] stream, forward and backward."""
+
+    def __init__(self, specs, H, nh, I, eps):
+        self.specs, self.H, self.nh, self.I, self.eps = specs, H, nh, I, eps
+
+    def make_prepared(self, device):
+        return [dict(qkv=PreparedWeight([sp.q, sp.k, sp.v], device), o=PreparedWeight([sp.o], device),
+                     w1=PreparedWeight([sp.w1], device), w2=PreparedWeight([sp.w2], device)) for sp in self.specs]
+
+    def forward(self, pw_layers, x32, x_hi, x_lo, am, B, S, p_hid, p_att, seed, row_post=None):
+        H, I, nh, M, dev = self.H, self.I, self.nh, B * S, x32.device
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
+        saved = []
+        for l, (sp, lw) in enumerate(zip(self.specs, pw_layers)):
+            ls = dict(x_hi=x_hi)
+            qkv32 = f32(M, 3 * H)
+            ops.gemm_nt(x_hi, x_lo, lw["qkv"].hi, lw["qkv"].lo, M, 3 * H, H, 3, EPI_F32, bias=lw["qkv"].bias,
+                        out32=qkv32)
+            ctx_hi, ctx_lo, lse = b16(M, H), b16(M, H), f32(B * nh * S)
+            ops.attn_fwd(qkv32, am, ctx_hi, ctx_lo, lse, B, S, nh, 64, p_att, seed(16 * l + 3))
+            z1 = f32(M, H)
+            ops.gemm_nt(ctx_hi, ctx_lo, lw["o"].hi, lw["o"].lo, M, H, H, 3, EPI_F32, bias=lw["o"].bias, out32=z1)
+            x1_32, x1_hi, x1_lo, mean1, rstd1 = f32(M, H), b16(M, H), b16(M, H), f32(M), f32(M)
+            ops.ln_fwd(z1, x32, None, sp.ln1.weight.detach(), sp.ln1.bias.detach(), self.eps, x1_32, x1_hi, x1_lo,
+                       mean1, rstd1, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
+            u16, h_hi, h_lo = b16(M, I), b16(M, I), b16(M, I)
+            ops.gemm_nt(x1_hi, x1_lo, lw["w1"].hi, lw["w1"].lo, M, I, H, 3, EPI_GELU_SPLIT, bias=lw["w1"].bias,
+                        out_hi=h_hi, out_lo=h_lo, aux16=u16)
+            z2 = f32(M, H)
+            ops.gemm_nt(h_hi, h_lo, lw["w2"].hi, lw["w2"].lo, M, H, I, 3, EPI_F32, bias=lw["w2"].bias, out32=z2)
+            x2_32, x2_hi, x2_lo, mean2, rstd2 = f32(M, H), b16(M, H), b16(M, H), f32(M), f32(M)
+            ops.ln_fwd(z2, x1_32, None, sp.ln2.weight.detach(), sp.ln2.bias.detach(), self.eps, x2_32, x2_hi, x2_lo,
+                       mean2, rstd2, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
+            ls.update(qkv32=qkv32, ctx_hi=ctx_hi, ctx_lo=ctx_lo, lse=lse, z1=z1, mean1=mean1, rstd1=rstd1,
+                      x1_hi=x1_hi, u16=u16, h_hi=h_hi, z2=z2, mean2=mean2, rstd2=rstd2)
+            saved.append(ls)
+            x32, x_hi, x_lo = x2_32, x2_hi, x2_lo
+        return x32, x_hi, x_lo, saved
+
+    def backward(self, pw_layers, saved, dy, am, B, S, p_hid, p_att, seed, ws, row_post=None):
+        """dy [M,H] fp32 = dL/d(stack output).  Returns (dL/d(stack input), per-layer grads in LayerSpec.params order)."""
+        H, I, nh, M, dev = self.H, self.I, self.nh, B * S, dy.device
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
+        b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
+        layer_grads = [None] * len(self.specs)
+        for l in reversed(range(len(self.specs))):
+            sp, lw, ls = self.specs[l], pw_layers[l], saved[l]
+            dz2, dt2 = f32(M, H), b16(M, H)
+            dg2, db2, dbias2 = f32(H), f32(H), f32(H)
+            ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, dg2, db2, dbias2,
+                       ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
+            du16 = b16(M, I)
+            ops.gemm_nt(dt2, None, lw["w2"].t_hi, None, M, I, H, 1, EPI_DGELU_BF16, out_hi=du16, aux16=ls["u16"])
+            dx1 = f32(M, H)
+            ops.gemm_nt(du16, None, lw["w1"].t_hi, None, M, H, I, 1, EPI_F32, resid=dz2, out32=dx1)
+            dW2 = _masked(dw_gemm(dt2, ls["h_hi"], M, H, I), sp.w2)
+            dW1 = _masked(dw_gemm(du16, ls["x1_hi"], M, I, H), sp.w1)
+            dbias1 = ops.colsum_bf16(du16, M, I, f32(I))
+            dz1, dt1 = f32(M, H), b16(M, H)
+            dg1, db1, dbias_o = f32(H), f32(H), f32(H)
+            ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, dg1, db1,
+                       dbias_o, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
+            dctx = f32(M, H)
+            ops.gemm_nt(dt1, None, lw["o"].t_hi, None, M, H, H, 1, EPI_F32, out32=dctx)
+            dWo = _masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), sp.o)
+            dqkv = b16(M, 3 * H)
+            ops.attn_bwd(ls["qkv32"], am, ls["ctx_hi"], ls["ctx_lo"], dctx, ls["lse"], dqkv, B, S, nh, 64, p_att,
+                         seed(16 * l + 3))
+            dx0 = f32(M, H)
+            ops.gemm_nt(dqkv, None, lw["qkv"].t_hi, None, M, H, 3 * H, 1, EPI_F32, resid=dz1, out32=dx0)
+            dWqkv = dw_gemm(dqkv, ls["x_hi"], M, 3 * H, H)
+            for i, lin in enumerate((sp.q, sp.k, sp.v)):
+                _masked(dWqkv[i * H:(i + 1) * H], lin)
+            dbqkv = ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H))
+            layer_grads[l] = [dWqkv[0:H], dbqkv[0:H], dWqkv[H:2 * H], dbqkv[H:2 * H], dWqkv[2 * H:], dbqkv[2 * H:],
+                              dWo, dbias_o, dg1, db1, dW1, dbias1, dW2, dbias2, dg2, db2]
+            dy = dx0
+            saved[l] = None  # release this layer's activations
+        return dy, layer_grads
+
+
+class EngineBase(object):
+    """Weight preparation (one launch per step), dropout seeds, dirty tracking shared by the UC2 and M3P engines."""
+
+    def _init_common(self, H, nh):
+        if H % nh != 0 or H // nh != 64:
+            raise ValueError("clg_vqa_amd: the native attention kernel needs head dim 64 (hidden %d / heads %d)" % (H, nh))
+        if H % 256 != 0:
             raise ValueError("clg_vqa_amd: hidden size must be a multiple of 256 for the native LayerNorm")
         self._prepared = None
         self._dirty = True
@@ -129,6 +230,60 @@ class UC2Engine(object):
         self.word_grad_sink = None
         self.base_seed = 0x5EED
         self.calls = 0
+
+    def mark_dirty(self):
+        """Call after updating parameters through raw pointers (the fused optimizer does)."""
+        self._dirty = True
+
+    def next_seed(self):
+        self.calls += 1
+        seed0 = (self.base_seed * 0x9E3779B1 + self.calls * 0x10001) & 0x7FFFFFFFFFFF
+        return lambda site: (seed0 * 4096 + site) & 0xFFFFFFFFFFFFFFFF
+
+    def prepared(self, device):
+        if self._prepared is None or self._prepared["device"] != device:
+            self._prepared = dict(device=device, img=PreparedWeight([self.image_linear()], device, need_t=False),
+                                  layers=self.stack.make_prepared(device))
+            self._dirty = True
+        pw = self._prepared
+        all_pw = [pw["img"]] + [lw[k] for lw in pw["layers"] for k in ("qkv", "o", "w1", "w2")]
+        if self._dirty or any(p._key() != p.key for p in all_pw):
+            desc = [r for p in all_pw for r in p.descriptors()]
+            ident = tuple((r[0], r[1]) for r in desc)
+            if pw.get("table_ident") != ident:
+                rows, tile0 = [], 0
+                for r in desc:
+                    rows.append(r + [tile0])
+                    tile0 += ((r[5] + 63) // 64) * ((r[6] + 63) // 64)
+                pw["table"] = torch.tensor(rows, dtype=torch.int64).to(device)
+                pw["table_ident"], pw["table_tiles"] = ident, tile0
+            ops.weight_prep_multi(pw["table"], pw["table"].shape[0], pw["table_tiles"])  # one launch per step
+            for p in all_pw:
+                p.refresh_bias()
+        self._dirty = False
+        return pw
+
+
+class UC2Engine(EngineBase):
+    """Binds a ``BertForVLTasks`` module tree (reference parameter names) to the native kernels."""
+
+    def __init__(self, model):
+        self.model = model
+        cfg = model.config
+        self.H, self.nh, self.I, self.eps = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size, cfg.layer_norm_eps
+        self.n_layers = len(model.bert.encoder.layer) // 2
+        self._init_common(self.H, self.nh)
+        specs = []
+        for l in range(self.n_layers):
+            at = model.bert.encoder.layer[2 * l]
+            ff = model.bert.encoder.layer[2 * l + 1]
+            sa, so = at.attention_self, at.attention_output
+            specs.append(LayerSpec(sa.query, sa.key, sa.value, so.dense, so.LayerNorm, ff.intermediate.dense,
+                                   ff.output.dense, ff.output.LayerNorm))
+        self.stack = LayerStack(specs, self.H, self.nh, self.I, self.eps)
+
+    def image_linear(self):
+        return self.model.bert.embeddings.image_embeddings
 
     # ---- parameters ------------------------------------------------------------------------------------------
     def param_list(self):
@@ -140,57 +295,9 @@ class UC2Engine(object):
               e.image_layer_norm.weight, e.image_layer_norm.bias,
               e.image_location_layer_norm.weight, e.image_location_layer_norm.bias,
               e.v_LayerNorm.weight, e.v_LayerNorm.bias]
-        for l in range(self.n_layers):
-            at = self.model.bert.encoder.layer[2 * l]
-            ff = self.model.bert.encoder.layer[2 * l + 1]
-            sa, so = at.attention_self, at.attention_output
-            for lin in (sa.query, sa.key, sa.value, so.dense):
-                ps += [linear_params(lin)[0], lin.bias]
-            ps += [so.LayerNorm.weight, so.LayerNorm.bias]
-            for lin in (ff.intermediate.dense, ff.output.dense):
-                ps += [linear_params(lin)[0], lin.bias]
-            ps += [ff.output.LayerNorm.weight, ff.output.LayerNorm.bias]
+        for sp in self.stack.specs:
+            ps += sp.params()
         return ps
-
-    def mark_dirty(self):
-        """Call after updating parameters through raw pointers (the fused optimizer does)."""
-        self._dirty = True
-
-    def prepared(self, device):
-        if self._prepared is None or self._prepared["device"] != device:
-            e = self.model.bert.embeddings
-            layers = []
-            for l in range(self.n_layers):
-                at = self.model.bert.encoder.layer[2 * l]
-                ff = self.model.bert.encoder.layer[2 * l + 1]
-                sa = at.attention_self
-                layers.append(dict(
-                    qkv=PreparedWeight([sa.query, sa.key, sa.value], device),
-                    o=PreparedWeight([at.attention_output.dense], device),
-                    w1=PreparedWeight([ff.intermediate.dense], device),
-                    w2=PreparedWeight([ff.output.dense], device)))
-            self._prepared = dict(device=device, img=PreparedWeight([e.image_embeddings], device, need_t=False),
-                                  layers=layers)
-            self._dirty = True
-        pw = self._prepared
-        all_pw = [pw["img"]] + [lw[k] for lw in pw["layers"] for k in ("qkv", "o", "w1", "w2")]
-        if self._dirty or any(p._key() != p.key for p in all_pw):
-            ptrs = tuple(r[0] for p in all_pw for r in p.descriptors())
-            if pw.get("table_ptrs") != ptrs or pw.get("table_masks") != tuple(r[1] for p in all_pw for r in p.descriptors()):
-                rows, tile0 = [], 0
-                for p in all_pw:
-                    for r in p.descriptors():
-                        rows.append(r + [tile0])
-                        tile0 += ((r[5] + 63) // 64) * ((r[6] + 63) // 64)
-                pw["table"] = torch.tensor(rows, dtype=torch.int64).to(device)
-                pw["table_ptrs"] = ptrs
-                pw["table_masks"] = tuple(r[1] for r in rows)
-                pw["table_tiles"] = tile0
-            ops.weight_prep_multi(pw["table"], pw["table"].shape[0], pw["table_tiles"])  # one launch per step
-            for p in all_pw:
-                p.refresh_bias()
-        self._dirty = False
-        return pw
 
     # ---- forward -------------------------------------------------------------------------------------------------
     def forward(self, ids, feats, locs, seg, tmask, imask, training):
@@ -203,13 +310,11 @@ class UC2Engine(object):
         B, T = ids.shape
         V, F = feats.shape[1], feats.shape[2]
         L = locs.shape[2]
-        S, H, I, nh = T + V, self.H, self.I, self.nh
+        S, H = T + V, self.H
         M, BT, BV = B * S, B * T, B * V
         p_hid = float(cfg.hidden_dropout_prob) if training else 0.0
         p_att = float(cfg.attention_probs_dropout_prob) if training else 0.0
-        self.calls += 1
-        seed0 = (self.base_seed * 0x9E3779B1 + self.calls * 0x10001) & 0x7FFFFFFFFFFF
-        seed = lambda site: (seed0 * 4096 + site) & 0xFFFFFFFFFFFFFFFF  # noqa: E731
+        seed = self.next_seed()
         pw = self.prepared(dev)
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
@@ -218,7 +323,7 @@ class UC2Engine(object):
         feats2 = feats.contiguous().view(BV, F)
         locs2 = locs.contiguous().view(BV, L)
         sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, ids=ids, seg=seg,
-                  locs=locs2, pw=pw, layers=[])
+                  locs=locs2, pw=pw)
 
         am = f32(M)
         ops.addmask(tmask, imask, am, B, T, V)
@@ -250,38 +355,7 @@ class UC2Engine(object):
                    seed=seed(2))
         sv.update(z_t=z_t, mean_t=mean_t, rstd_t=rstd_t, f_hi=f_hi, z_i=z_i, mean_i=mean_i, rstd_i=rstd_i,
                   z_l=z_l, mean_l=mean_l, rstd_l=rstd_l, z_v=a32, mean_v=mean_v, rstd_v=rstd_v)
-
-        for l in range(self.n_layers):
-            at = self.model.bert.encoder.layer[2 * l]
-            ff = self.model.bert.encoder.layer[2 * l + 1]
-            lw = pw["layers"][l]
-            ls = dict(x_hi=x_hi)
-            # --- attention sub-layer (encoders.py:229-359 + :399-425) ---
-            qkv32 = f32(M, 3 * H)
-            ops.gemm_nt(x_hi, x_lo, lw["qkv"].hi, lw["qkv"].lo, M, 3 * H, H, 3, EPI_F32, bias=lw["qkv"].bias,
-                        out32=qkv32)
-            ctx_hi, ctx_lo, lse = b16(M, H), b16(M, H), f32(B * nh * S)
-            ops.attn_fwd(qkv32, am, ctx_hi, ctx_lo, lse, B, S, nh, 64, p_att, seed(16 * l + 3))
-            z1 = f32(M, H)
-            ops.gemm_nt(ctx_hi, ctx_lo, lw["o"].hi, lw["o"].lo, M, H, H, 3, EPI_F32, bias=lw["o"].bias, out32=z1)
-            x1_32, x1_hi, x1_lo, mean1, rstd1 = f32(M, H), b16(M, H), b16(M, H), f32(M), f32(M)
-            lno = at.attention_output.LayerNorm
-            ops.ln_fwd(z1, x32, None, lno.weight.detach(), lno.bias.detach(), self.eps, x1_32, x1_hi, x1_lo, mean1,
-                       rstd1, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
-            # --- feed-forward sub-layer (encoders.py:487-502 + :542-567) ---
-            u16, h_hi, h_lo = b16(M, I), b16(M, I), b16(M, I)
-            ops.gemm_nt(x1_hi, x1_lo, lw["w1"].hi, lw["w1"].lo, M, I, H, 3, EPI_GELU_SPLIT, bias=lw["w1"].bias,
-                        out_hi=h_hi, out_lo=h_lo, aux16=u16)
-            z2 = f32(M, H)
-            ops.gemm_nt(h_hi, h_lo, lw["w2"].hi, lw["w2"].lo, M, H, I, 3, EPI_F32, bias=lw["w2"].bias, out32=z2)
-            x2_32, x2_hi, x2_lo, mean2, rstd2 = f32(M, H), b16(M, H), b16(M, H), f32(M), f32(M)
-            lnf = ff.output.LayerNorm
-            ops.ln_fwd(z2, x1_32, None, lnf.weight.detach(), lnf.bias.detach(), self.eps, x2_32, x2_hi, x2_lo, mean2,
-                       rstd2, M, H, p_pre=p_hid, seed=seed(16 * l + 5))
-            ls.update(qkv32=qkv32, ctx_hi=ctx_hi, ctx_lo=ctx_lo, lse=lse, z1=z1, mean1=mean1, rstd1=rstd1,
-                      x1_hi=x1_hi, u16=u16, h_hi=h_hi, z2=z2, mean2=mean2, rstd2=rstd2)
-            sv["layers"].append(ls)
-            x32, x_hi, x_lo = x2_32, x2_hi, x2_lo
+        x32, x_hi, x_lo, sv["layers"] = self.stack.forward(pw["layers"], x32, x_hi, x_lo, am, B, S, p_hid, p_att, seed)
         return x32.view(B, S, H), sv
 
     # ---- backward ------------------------------------------------------------------------------------------------
@@ -290,62 +364,15 @@ class UC2Engine(object):
         cfg = self.model.config
         emb = self.model.bert.embeddings
         B, T, V, F, L, S = sv["B"], sv["T"], sv["V"], sv["F"], sv["L"], sv["S"]
-        H, I, nh = self.H, self.I, self.nh
+        H = self.H
         M, BT, BV = B * S, B * T, B * V
         dev = dx.device
         p_hid, p_att, seed, pw, am = sv["p_hid"], sv["p_att"], sv["seed"], sv["pw"], sv["am"]
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
         ws = ops.ln_bwd_ws(M, H, dev)
-        dy = dx.contiguous().view(M, H)
-        layer_grads = [None] * self.n_layers
-
-        def masked(dw, lin, rows=None):
-            m = linear_params(lin)[1]
-            if m is not None:  # SFT: grad(weight_orig) = grad(weight) (*) mask
-                ops.mask_mul(dw, m, dw)
-            return dw
-
-        for l in reversed(range(self.n_layers)):
-            at = self.model.bert.encoder.layer[2 * l]
-            ff = self.model.bert.encoder.layer[2 * l + 1]
-            lw, ls = pw["layers"][l], sv["layers"][l]
-            # feed-forward sub-layer
-            lnf = ff.output.LayerNorm
-            dz2, dt2 = f32(M, H), b16(M, H)
-            dg2, db2, dbias2 = f32(H), f32(H), f32(H)
-            ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], lnf.weight.detach(), dz2, dt2, None, dg2, db2, dbias2,
-                       ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5))
-            du16 = b16(M, I)
-            ops.gemm_nt(dt2, None, lw["w2"].t_hi, None, M, I, H, 1, EPI_DGELU_BF16, out_hi=du16, aux16=ls["u16"])
-            dx1 = f32(M, H)
-            ops.gemm_nt(du16, None, lw["w1"].t_hi, None, M, H, I, 1, EPI_F32, resid=dz2, out32=dx1)
-            dW2 = masked(dw_gemm(dt2, ls["h_hi"], M, H, I), ff.output.dense)
-            dW1 = masked(dw_gemm(du16, ls["x1_hi"], M, I, H), ff.intermediate.dense)
-            dbias1 = ops.colsum_bf16(du16, M, I, f32(I))
-            # attention sub-layer
-            lno = at.attention_output.LayerNorm
-            dz1, dt1 = f32(M, H), b16(M, H)
-            dg1, db1, dbias_o = f32(H), f32(H), f32(H)
-            ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], lno.weight.detach(), dz1, dt1, None, dg1, db1, dbias_o,
-                       ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
-            dctx = f32(M, H)
-            ops.gemm_nt(dt1, None, lw["o"].t_hi, None, M, H, H, 1, EPI_F32, out32=dctx)
-            dWo = masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), at.attention_output.dense)
-            dqkv = b16(M, 3 * H)
-            ops.attn_bwd(ls["qkv32"], am, ls["ctx_hi"], ls["ctx_lo"], dctx, ls["lse"], dqkv, B, S, nh, 64, p_att,
-                         seed(16 * l + 3))
-            dx0 = f32(M, H)
-            ops.gemm_nt(dqkv, None, lw["qkv"].t_hi, None, M, H, 3 * H, 1, EPI_F32, resid=dz1, out32=dx0)
-            dWqkv = dw_gemm(dqkv, ls["x_hi"], M, 3 * H, H)
-            sa = at.attention_self
-            for i, lin in enumerate((sa.query, sa.key, sa.value)):
-                masked(dWqkv[i * H:(i + 1) * H], lin)
-            dbqkv = ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H))
-            layer_grads[l] = [dWqkv[0:H], dbqkv[0:H], dWqkv[H:2 * H], dbqkv[H:2 * H], dWqkv[2 * H:], dbqkv[2 * H:],
-                              dWo, dbias_o, dg1, db1, dW1, dbias1, dW2, dbias2, dg2, db2]
-            dy = dx0
-            sv["layers"][l] = None  # release this layer's activations
+        dy, layer_grads = self.stack.backward(pw["layers"], sv["layers"], dx.contiguous().view(M, H), am, B, S, p_hid,
+                                              p_att, seed, ws)
 
         # --- embeddings backward (dy = dL/dX0 [M,H]) ---
         type_w = emb.new_token_type_embeddings.weight
@@ -361,7 +388,7 @@ class UC2Engine(object):
         dimg16, dg_i, db_i, dbias_img = b16(BV, H), f32(H), f32(H), f32(H)
         ops.ln_bwd(dz_v, sv["z_i"], sv["mean_i"], sv["rstd_i"], emb.image_layer_norm.weight.detach(), None, dimg16,
                    None, dg_i, db_i, dbias_img, ws, BV, H)
-        dWimg = masked(dw_gemm(dimg16, sv["f_hi"], BV, H, F), emb.image_embeddings)
+        dWimg = _masked(dw_gemm(dimg16, sv["f_hi"], BV, H, F), emb.image_embeddings)
         dloc32, dg_l, db_l = f32(BV, H), f32(H), f32(H)
         ops.ln_bwd(dz_v, sv["z_l"], sv["mean_l"], sv["rstd_l"], emb.image_location_layer_norm.weight.detach(), None,
                    None, dloc32, dg_l, db_l, None, ws, BV, H)
@@ -374,14 +401,15 @@ class UC2Engine(object):
                    db_e, None, ws, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
         ops.embed_text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id))
         dtype_[1] += dtype1  # image_token_type_embeddings is new_token_type_embeddings (embeddings.py:628)
-        grads = [None if use_sink else dword, dpos, dtype_, dg_e, db_e, dWimg, dbias_img, dWl, dbl, dg_i, db_i, dg_l, db_l, dg_v, db_v]
+        grads = [None if use_sink else dword, dpos, dtype_, dg_e, db_e, dWimg, dbias_img, dWl, dbl, dg_i, db_i, dg_l,
+                 db_l, dg_v, db_v]
         for lg in layer_grads:
             grads += lg
         return grads
 
 
-class UC2TrunkFunction(torch.autograd.Function):
-    """autograd boundary of the native trunk: (batch, *params) -> X_final [B,S,H]."""
+class TrunkFunction(torch.autograd.Function):
+    """autograd boundary of a native trunk: (batch, *params) -> X_final [B,S,H]."""
 
     @staticmethod
     def forward(ctx, engine, training, ids, feats, locs, seg, tmask, imask, *params):
@@ -397,3 +425,6 @@ class UC2TrunkFunction(torch.autograd.Function):
         needs = ctx.needs_input_grad[8:]
         grads = [g if need else None for g, need in zip(grads, needs)]
         return (None,) * 8 + tuple(grads)
+
+
+UC2TrunkFunction = TrunkFunction

@@ -96,9 +96,11 @@ def attn_bwd(qkv32, addmask, ctx_hi, ctx_lo, dctx32, lse, dqkv16, B, S, nh, dh, 
 
 
 def ln_fwd(y, resid, addvec, gamma, beta, eps, out32, out_hi, out_lo, mean, rstd, M, H, group=None, out_stride=0,
-           out_off=0, p_pre=0.0, p_post=0.0, seed=0):
+           out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None):
     group = M if group is None else group
-    _lib.check(_lib.lib().vl_ln_fwd(_p(y), _p(resid), _p(addvec), _p(gamma), _p(beta), float(eps), _p(out32),
+    arows = 1 if addvec is None or addvec.dim() == 1 else addvec.shape[0]
+    _lib.check(_lib.lib().vl_ln_fwd(_p(y), _p(resid), _p(addvec), arows, _p(row_pre), _p(row_post), _p(gamma),
+                                    _p(beta), float(eps), _p(out32),
                                     _p(out_hi), _p(out_lo), _p(mean), _p(rstd), M, H, group, out_stride, out_off,
                                     float(p_pre), float(p_post), int(seed), _stream()), "vl_ln_fwd")
 
@@ -108,9 +110,10 @@ def ln_bwd_ws(M, H, device):
 
 
 def ln_bwd(dy, z, mean, rstd, gamma, dz, dpre16, dpre32, dgamma, dbeta, dbias, ws, M, H, group=None, out_stride=0,
-           out_off=0, p_pre=0.0, p_post=0.0, seed=0):
+           out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None):
     group = M if group is None else group
-    _lib.check(_lib.lib().vl_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(dz), _p(dpre16), _p(dpre32),
+    _lib.check(_lib.lib().vl_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(row_pre), _p(row_post), _p(dz),
+                                    _p(dpre16), _p(dpre32),
                                     _p(dgamma), _p(dbeta), _p(dbias), _p(ws), M, H, group, out_stride, out_off,
                                     float(p_pre), float(p_post), int(seed), _stream()), "vl_ln_bwd")
 
@@ -174,6 +177,15 @@ def embed_text_fwd(ids, seg, word, pos, typ, z32, B, T, H, pad_id):
 def embed_text_bwd(ids, seg, dz32, dword, dpos, dtyp, B, T, H, pad_id):
     _lib.check(_lib.lib().vl_embed_text_bwd(_p(ids), _p(seg), _p(dz32), _p(dword), _p(dpos), _p(dtyp), B, T, H,
                                             pad_id, _stream()), "vl_embed_text_bwd")
+
+
+def embed_gather_fwd(ids, table, out32, R, H):
+    _lib.check(_lib.lib().vl_embed_gather_fwd(_p(ids), _p(table), _p(out32), R, H, _stream()), "vl_embed_gather_fwd")
+
+
+def embed_scatter_add(ids, dz32, dtable, R, H, pad_id=-1):
+    _lib.check(_lib.lib().vl_embed_scatter_add(_p(ids), _p(dz32), _p(dtable), R, H, pad_id, _stream()),
+               "vl_embed_scatter_add")
 
 
 def loc_linear_fwd(loc, w, b, y32, R, L, H):

@@ -88,15 +88,18 @@ int vl_attn_bwd(const float* qkv32, const float* addmask, const void* ctx_hi, co
  * kernels layer_norm_cuda_kernel.cu:279-322, :403-637) == BertLayerNorm (encoders.py:44-62), fused with the
  * surrounding eager ops of BertGatedSelfOutput / BertGatedOutput (encoders.py:411-425, :553-567) and of
  * UC2Embeddings (embeddings.py:653-666):
- *     z   = dropout_pre(y) + resid + addvec            (resid, addvec may be NULL; z is written back over y)
- *     out = dropout_post(gamma * (z - mean) * rsqrt(var + eps) + beta)        biased var, eps inside sqrt
+ *     z   = (dropout_pre(y) + resid + addvec[r % addvec_rows]) * row_pre[r]     (each term optional; z overwrites y)
+ *     out = dropout_post(gamma * (z - mean) * rsqrt(var + eps) + beta) * row_post[r]      biased var, eps in sqrt
+ * addvec is an [addvec_rows, H] table (1 row = a broadcast vector: UC2's type embedding; V or T rows = M3P's
+ * position embeddings over the [image ; text] stream, m3p_transformer.py:929-933); row_pre / row_post are the [M]
+ * multiplicative length masks of M3P (`tensor *= mask`, m3p_transformer.py:937, :955).
  * Output row r of the M input rows goes to row (r / group)*out_stride + out_off + (r % group) of out32/out_hi/
  * out_lo (group == M, out_stride == 0, out_off == 0 for the identity map) -- this is how the text rows and box
  * rows are interleaved into the single [B, S, H] stream.  H must be a multiple of 256, H <= 2048.
  * mean, rstd: [M] fp32 saved for backward.  out_hi/out_lo may be NULL.
  * ------------------------------------------------------------------------------------------------------------ */
-int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, const float* gamma, const float* beta,
-              float eps, float* out32, void* out_hi, void* out_lo, float* mean, float* rstd, int64_t M, int64_t H,
+int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, int64_t addvec_rows, const float* row_pre,
+              const float* row_post, const float* gamma, const float* beta, float eps, float* out32, void* out_hi, void* out_lo, float* mean, float* rstd, int64_t M, int64_t H,
               int64_t group, int64_t out_stride, int64_t out_off, float p_pre, float p_post, uint64_t seed,
               void* stream);
 /* Backward: dy32 is read through the same row map; dz32 [M,H] = dL/dz (what flows to the residual branch);
@@ -105,7 +108,7 @@ int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, const f
  * gradient; may be NULL).  partial_ws: >= vl_ln_bwd_ws_floats(M, H) floats of scratch. */
 int64_t vl_ln_bwd_ws_floats(int64_t M, int64_t H);
 int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd, const float* gamma,
-              float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta, float* dbias,
+              const float* row_pre, const float* row_post, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta, float* dbias,
               float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
               float p_pre, float p_post, uint64_t seed, void* stream);
 
@@ -153,6 +156,11 @@ int vl_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word,
                       const float* type, float* z32, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream);
 int vl_embed_text_bwd(const int64_t* ids, const int64_t* seg, const float* dz32, float* dword, float* dpos,
                       float* dtype, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream);
+/* plain row gather out[r,:] = table[ids[r],:] and its scatter-add (atomics; rows with ids[r] == pad_id skipped; pass
+ * pad_id = -1 for none) -- M3P's text embedding `self.embeddings(x)` (m3p_transformer.py:908). */
+int vl_embed_gather_fwd(const int64_t* ids, const float* table, float* out32, int64_t R, int64_t H, void* stream);
+int vl_embed_scatter_add(const int64_t* ids, const float* dz32, float* dtable, int64_t R, int64_t H, int64_t pad_id,
+                         void* stream);
 int vl_loc_linear_fwd(const float* loc, const float* w, const float* b, float* y32, int64_t R, int64_t L, int64_t H,
                       void* stream);
 /* dw [H,L], db [H] are ACCUMULATED with atomics: zero them first. */
