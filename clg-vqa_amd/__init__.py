@@ -6,5 +6,6 @@ reference's for this path: ``BertConfig`` / ``M3PConfig`` (volta/volta/config.py
 fine-tuning helpers (volta/train_task_prunning.py, volta/train_task_sft.py).
 """
 from .config import BertConfig, M3PConfig, TaskCfg, load_task_cfg  # noqa: F401
+# BertForVLTasks: clg_vqa_amd.encoders ; M3PForVLTasks: clg_vqa_amd.m3p (imported lazily: they load libvlhip.so)
 
 __version__ = "0.1.0"

@@ -46,7 +46,8 @@ _M3P_DEFAULTS = dict(
     v_hidden_size=768, norm_embeddings=False, fixed_layers=[], fusion_act="relu",
     clf_hidden_size=1536, model="bert", n_langs=100, n_words=250002, eos_index=2, pad_index=1,
     emb_dim=768, n_layers=12, dropout=0.1, attention_dropout=0.1, gelu_activation=True,
-    sinusoidal_embeddings=False, fusion_method="text",
+    sinusoidal_embeddings=False, fusion_method="text", refine_layers=6, attention_setting="v1",
+    use_externel_att=False, max_boxes=100,
 )
 
 

@@ -66,8 +66,9 @@ class FlatArena(object):
     def gather_grads(self):
         """Copy the autograd-produced gradients into the flat gradient arena (params without a grad -- e.g.
         M3P's never-used modules -- contribute zeros, like apex skipping ``grad is None``)."""
-        dst, src = [], []
+        dst, src, has = [], [], []
         for (_, p, _, _), gv in zip(self.groups, self.grad_views):
+            has.append(p.grad is not None)
             if p.grad is not None:
                 dst.append(gv)
                 src.append(p.grad)
@@ -75,6 +76,7 @@ class FlatArena(object):
             torch._foreach_copy_(dst, src)
         for _, p, _, _ in self.groups:
             p.grad = None
+        return has
 
 
 class GradReducer(object):
@@ -132,12 +134,14 @@ class FusedAdamW(object):
         self._scale = torch.zeros(1, dtype=torch.float32, device=device)
         if hasattr(model, "mark_weights_dirty"):
             model.mark_weights_dirty()
+        self._active, self._sink_index = None, -1
         eng = getattr(model, "engine", None)
         if eng is not None:  # scatter the word-embedding gradient straight into the (zeroed) arena
-            we = model.bert.embeddings.word_embeddings.weight
-            for (_, p, _, _), gv in zip(self.groups, self.arena.grad_views):
-                if p is we:
+            emb = model.bert.embeddings.word_embeddings if hasattr(model.bert, "embeddings") else model.bert.encoder.embeddings
+            for i, ((_, p, _, _), gv) in enumerate(zip(self.groups, self.arena.grad_views)):
+                if p is emb.weight:
                     eng.word_grad_sink = gv
+                    self._sink_index = i
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "opt_step": self.opt_step,
@@ -162,7 +166,14 @@ class FusedAdamW(object):
     def step(self):
         """reduce -> clip -> AdamW -> scheduler step -> zero_grad  (train_task.py:326-338)."""
         a = self.arena
-        a.gather_grads()
+        has = a.gather_grads()
+        # parameters that received no gradient are skipped entirely, like `if p.grad is None: continue` in
+        # pytorch_transformers.AdamW (no moment decay, no weight decay): M3P's 93 M never-used parameters
+        active = tuple(h or (i == self._sink_index) for i, h in enumerate(has))
+        if active != self._active:
+            self._active = active
+            lr = [g[2] if act else 0.0 for g, act in zip(self.groups, active)]
+            self.seg_lr.copy_(torch.tensor(lr, dtype=torch.float32))
         post = self.reducer.allreduce_(a.grad)
         self._sumsq.zero_()
         ops.sumsq(a.grad, self._sumsq)

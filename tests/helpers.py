@@ -17,9 +17,9 @@ def load_golden(name):
     return {k: z[k] for k in z.files}
 
 
-def golden_config(g):
-    from clg_vqa_amd.config import BertConfig
-    return BertConfig.from_dict(json.loads(bytes(g["cfg_json"]).decode()))
+def golden_config(g, m3p=False):
+    from clg_vqa_amd.config import BertConfig, M3PConfig
+    return (M3PConfig if m3p else BertConfig).from_dict(json.loads(bytes(g["cfg_json"]).decode()))
 
 
 def golden_batch(g):

@@ -66,3 +66,32 @@ def test_from_pretrained_local_file(tmp_path):
         assert torch.equal(v, m2.state_dict()[k]), k
     assert BertForVLTasks.from_pretrained(str(tmp_path / "nope.bin"), config=cfg, task_cfg=TASK_CFG,
                                           task_ids=["TASK15"]) is None
+
+
+def test_m3p_state_dict_surface_matches_reference_fixture():
+    import json
+    from clg_vqa_amd.m3p import M3PForVLTasks
+    g = load_golden("m3p_small.npz")
+    cfg = golden_config(g, m3p=True)
+    m = M3PForVLTasks(cfg, TASK_CFG, ["TASK15"])
+    sd = m.state_dict()
+    assert list(sd.keys()) == bytes(g["state_keys"]).decode().split("\n")
+    assert [list(v.shape) for v in sd.values()] == json.loads(bytes(g["state_shapes"]).decode())
+    assert len(m.engine.param_list()) == 10 + cfg.n_layers * 16
+
+
+def test_m3p_full_config_census_on_meta_device():
+    from clg_vqa_amd.m3p import M3PForVLTasks
+    import json as _json
+    import os
+    cfg = dict(attention_probs_dropout_prob=0.1, hidden_act="gelu", hidden_dropout_prob=0.1, hidden_size=768,
+               initializer_range=0.02, intermediate_size=3072, max_position_embeddings=514, n_heads=12, pooler_size=768,
+               type_vocab_size=1, vocab_size=250002, pad_token_id=1, num_locs=5, image_embeddings="m3p",
+               model="roberta", v_feature_size=2048, v_hidden_size=768, norm_embeddings=True, fusion_method="text",
+               itm_dim=1, clf_hidden_size=1536)  # volta/config/m3p_base.json
+    with torch.device("meta"):
+        m = M3PForVLTasks(M3PConfig.from_dict(cfg), TASK_CFG, ["TASK15"])
+    assert sum(p.numel() for p in m.parameters()) == 376903735
+    with_grad = sum(p.numel() for p in m.engine.param_list()) + m.bert.pooler.dense.weight.numel() + \
+        m.bert.pooler.dense.bias.numel() + sum(p.numel() for p in m.clfs_dict.parameters())
+    assert with_grad == 283638066  # parameters that receive gradients

@@ -81,3 +81,34 @@ def test_sft_masked_grad():
     (y * y).sum().backward()
     np.testing.assert_allclose(w.grad.numpy(), g["sft_grad_orig"], rtol=1e-5, atol=1e-7)
     assert np.all(w.grad.numpy()[g["sft_mask"] == 0] == 0)
+
+
+def test_m3p_oracle_matches_reference_fixture():
+    from oracle import m3p_oracle as M
+    g = load_golden("m3p_small.npz")
+    config = golden_config(g, m3p=True)
+    model = M.OracleM3PForVLTasks(config, TASK_CFG, ["TASK15"])
+    sd = seeded_state_dict(model.state_dict(), seed=int(g["seed"]))
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    batch = golden_batch(g)
+    loss, score, logits = O.forward_train(model, batch)
+    np.testing.assert_allclose(logits.detach().numpy(), g["logits"], rtol=1e-4, atol=2e-5)
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    names = bytes(g["grad_names"]).decode().split("\n")
+    params = dict(model.named_parameters())
+    got_names = {n for n, p in params.items() if p.grad is not None}
+    # the reference registers the pooler under both bert.encoder.pooled_layer and bert.pooler
+    assert {n.replace("bert.pooler.", "bert.encoder.pooled_layer.") for n in names} == \
+        {n.replace("bert.pooler.", "bert.encoder.pooled_layer.") for n in got_names}
+    for n in names:
+        ref = g["grad::" + n]
+        pn = n if n in params else n.replace("bert.pooler.", "bert.encoder.pooled_layer.")
+        got = grad_digest(params[pn].grad)
+        if n.endswith("k_lin.bias"):  # mathematically zero gradient (softmax shift invariance)
+            assert got[-1] <= 1e-4 * g["grad::" + n.replace("k_lin.bias", "q_lin.bias")][-1], n
+            continue
+        scale = max(ref[-1], 1e-3)
+        np.testing.assert_allclose(got[:256], ref[:256], rtol=2e-4, atol=2e-5 * scale, err_msg=n)
+        assert abs(got[-1] - ref[-1]) <= 1e-4 * scale, n
