@@ -47,6 +47,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int alias_rows;               // debug / timing experiment (0 = off)
   int vec;                      // 1: leading dimensions / pointers allow the 16-byte (fp32) / 8-byte (bf16) epilogue
+  int splits;                   // TN kernel: number of K-ranges (1-D grid over splits x tiles)
   int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
 };
 
@@ -300,13 +301,18 @@ __global__ __launch_bounds__(1024, 4) void gemm2_tn_kernel(GemmArgs p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int nwg = p.tiles_m * p.tiles_n;
+  // 1-D grid over (split, tile): the workgroups resident on one XCD (bid % 8) get a contiguous range of the
+  // split-major work list, i.e. (almost) one K-range of the whole output -> each K-range of dY and X is pulled from
+  // HBM by one XCD's L2 only, instead of by every XCD that happens to host one of its tiles.
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int nwg = tiles * p.splits;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = swz / p.tiles_n, tn = swz - tm * p.tiles_n;
+  const int split = swz / tiles, tile = swz - split * tiles;
+  const int tm = tile / p.tiles_n, tn = tile - tm * p.tiles_n;
   const int row0 = tm * BM2, col0 = tn * BN;
-  const int kbeg = blockIdx.y * p.k_len;
+  const int kbeg = split * p.k_len;
   const int kend = min(p.K, kbeg + p.k_len);
   const int nk = (kend - kbeg) / 64;
 
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(1024, 4) void gemm2_tn_kernel(GemmArgs p) {
     __syncthreads();
   }
 
-  float* out32 = p.out32 + (long)blockIdx.y * p.slab_stride;
+  float* out32 = p.out32 + (long)split * p.slab_stride;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = row0 + wm * (16 * MT) + i * 16 + (lane & 15);
@@ -725,6 +731,7 @@ extern "C" int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int6
   const int bn = (N % 256 == 0 || N > 1024) ? 256 : 128;
   g.tiles_m = (int)((M + 255) / 256);
   g.tiles_n = (int)((N + bn - 1) / bn);
+  g.splits = eff;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = 2 * (size_t)(64 * 512 + 64 * bn * 2);
   hipError_t e = bn == 256 ? hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_tn_kernel<256>),
@@ -733,9 +740,9 @@ extern "C" int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int6
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_tn_splitk: hipFuncSetAttribute: %s", hipGetErrorString(e));
   if (bn == 256)
-    hipLaunchKernelGGL((gemm2_tn_kernel<256>), dim3(g.tiles_m * g.tiles_n, eff), dim3(1024), lds, s, g);
+    hipLaunchKernelGGL((gemm2_tn_kernel<256>), dim3(g.tiles_m * g.tiles_n * eff), dim3(1024), lds, s, g);
   else
-    hipLaunchKernelGGL((gemm2_tn_kernel<128>), dim3(g.tiles_m * g.tiles_n, eff), dim3(1024), lds, s, g);
+    hipLaunchKernelGGL((gemm2_tn_kernel<128>), dim3(g.tiles_m * g.tiles_n * eff), dim3(1024), lds, s, g);
   VL_CHECK_LAUNCH("vl_gemm_tn_splitk");
   if (eff > 1) {
     const long n4 = (long)(M * N / 4);

@@ -30,13 +30,18 @@ def main():
     L = _lib.lib()
     shapes = [("qkv   fwd", 14336, 2304, 768), ("oproj fwd", 14336, 768, 768), ("ffn1  fwd", 14336, 3072, 768),
               ("ffn2  fwd", 14336, 768, 3072), ("small-A  ", 2048, 768, 3072)]
-    variants = [("generic", dict(g=1, bn=0)), ("bn256", dict(g=0, bn=256)), ("bn192", dict(g=0, bn=192)),
+    variants = [("generic", dict(g=1, bn=0)), ("bn256-w8", dict(g=0, bn=256, wr=2)), ("bn192-w8", dict(g=0, bn=192, wr=2)),
                 ("bn256-w16", dict(g=0, bn=256, wr=4)), ("bn192-w16", dict(g=0, bn=192, wr=4))]
     for passes in (1, 3):
         print("== passes %d ==" % passes)
         for name, M, N, K in shapes:
-            a = torch.randn(M, K, device=DEV).to(BF16)
-            al = torch.randn(M, K, device=DEV).to(BF16)
+            # rotate through enough distinct A operands to defeat the 256 MiB Infinity Cache (HBM-cold, like in the
+            # training step where A was produced by an earlier kernel)
+            nbuf = max(2, int(600e6 // (M * K * 2 * (2 if passes == 3 else 1))) + 1)
+            a_list = [torch.randn(M, K, device=DEV).to(BF16) for _ in range(nbuf)]
+            al_list = [torch.randn(M, K, device=DEV).to(BF16) for _ in range(nbuf if passes == 3 else 1)]
+            it = [0]
+            a = a_list[0]; al = al_list[0]
             b = torch.randn(N, K, device=DEV).to(BF16)
             bl = torch.randn(N, K, device=DEV).to(BF16)
             out = torch.empty(M, N, device=DEV)
@@ -46,13 +51,17 @@ def main():
                 L.vl_debug_set(1, v["bn"])
                 L.vl_debug_set(3, v.get("alias", 0))
                 L.vl_debug_set(4, v.get("wr", 2))
-                us = bench(lambda: ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, out32=out))
+                def run():
+                    it[0] += 1
+                    ops.gemm_nt(a_list[it[0] % nbuf], al_list[it[0] % len(al_list)], b, bl, M, N, K, passes, EPI_F32,
+                                out32=out)
+                us = bench(run)
                 row.append("%s %7.1f us %6.0f TF" % (vname, us, 2.0 * M * N * K / us / 1e6))
             print("%s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
     L.vl_debug_set(1, 0)
     L.vl_debug_set(2, 0)
     L.vl_debug_set(3, 0)
-    L.vl_debug_set(4, 2)
+    L.vl_debug_set(4, 4)
 
 
 if __name__ == "__main__":
