@@ -141,15 +141,21 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sft", action="store_true", help="configs[2]: train under a Bernoulli(0.59) SFT mask")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank logic on a single GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = local_rank % max(1, torch.cuda.device_count())  # gloo rehearsal: several ranks on one GPU
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

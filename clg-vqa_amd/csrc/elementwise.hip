@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const int64_t* __re
   float* tr = dtype + seg[r] * (long)H;
   for (int c = lane; c < H; c += 64) {
     const float g = dz[r * H + c];
-    if (id != pad) atomicAdd(wr + c, g);
+    if (dword && id != pad) atomicAdd(wr + c, g);
     atomicAdd(pr + c, g);
     atomicAdd(tr + c, g);
   }
@@ -438,7 +438,7 @@ extern "C" int vl_embed_text_fwd(const int64_t* ids, const int64_t* seg, const f
 }
 extern "C" int vl_embed_text_bwd(const int64_t* ids, const int64_t* seg, const float* dz32, float* dword, float* dpos,
                                  float* dtype, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream) {
-  VL_CHECK_ARG(ids && seg && dz32 && dword && dpos && dtype && B > 0 && T > 0 && H > 0, "vl_embed_text_bwd: bad arguments");
+  VL_CHECK_ARG(ids && seg && dz32 && dpos && dtype && B > 0 && T > 0 && H > 0, "vl_embed_text_bwd: bad arguments");
   hipLaunchKernelGGL(embed_text_bwd_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
                      seg, dz32, dword, dpos, dtype, (int)B, (int)T, (int)H, pad_id);
   VL_CHECK_LAUNCH("vl_embed_text_bwd");

@@ -228,12 +228,24 @@ class EngineBase(object):
         # into directly (FusedAdamW installs a view of its flat gradient arena; the arena is re-zeroed by the
         # optimizer kernel).  Saves the 768 MB zero-fill and the 768 MB copy per step of the dense path.
         self.word_grad_sink = None
+        # multi-GPU: instead of scattering, hand (token ids, gradient rows) to the reducer, which exchanges the
+        # <= B*T touched rows sparsely (all-gather) instead of all-reducing the dense 768 MB table gradient
+        self.defer_word_grad = False
+        self.pending_word_grad = None
         self.base_seed = 0x5EED
         self.calls = 0
 
     def mark_dirty(self):
         """Call after updating parameters through raw pointers (the fused optimizer does)."""
         self._dirty = True
+
+    def _push_word_grad(self, ids, rows, pad_id):
+        rows = rows * (ids != pad_id).to(rows.dtype).unsqueeze(1)  # the pad row receives no gradient
+        if self.pending_word_grad is None:
+            self.pending_word_grad = (ids, rows)
+        else:  # gradient accumulation over micro-batches
+            self.pending_word_grad = (torch.cat([self.pending_word_grad[0], ids]),
+                                      torch.cat([self.pending_word_grad[1], rows]))
 
     def next_seed(self):
         self.calls += 1
@@ -378,7 +390,8 @@ class UC2Engine(EngineBase):
         type_w = emb.new_token_type_embeddings.weight
         sink = self.word_grad_sink
         use_sink = sink is not None and sink.shape == emb.word_embeddings.weight.shape and sink.device == dev
-        dword = sink if use_sink else torch.zeros_like(emb.word_embeddings.weight)
+        defer = use_sink and self.defer_word_grad
+        dword = None if defer else (sink if use_sink else torch.zeros_like(emb.word_embeddings.weight))
         dpos = torch.zeros_like(emb.position_embeddings.weight)
         dtype_ = torch.zeros_like(type_w)
         # box rows
@@ -400,6 +413,8 @@ class UC2Engine(EngineBase):
         ops.ln_bwd(dy, sv["z_t"], sv["mean_t"], sv["rstd_t"], emb.LayerNorm.weight.detach(), dz_t, None, None, dg_e,
                    db_e, None, ws, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
         ops.embed_text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id))
+        if defer:
+            self._push_word_grad(sv["ids"].view(-1), dz_t, int(cfg.pad_token_id))
         dtype_[1] += dtype1  # image_token_type_embeddings is new_token_type_embeddings (embeddings.py:628)
         grads = [None if use_sink else dword, dpos, dtype_, dg_e, db_e, dWimg, dbias_img, dWl, dbl, dg_i, db_i, dg_l,
                  db_l, dg_v, db_v]

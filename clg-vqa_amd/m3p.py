@@ -225,12 +225,16 @@ class M3PEngine(EngineBase):
         dpos = torch.zeros_like(e.position_embeddings.weight)
         sink = self.word_grad_sink
         use_sink = sink is not None and sink.shape == e.embeddings.weight.shape and sink.device == dev
-        dword = sink if use_sink else torch.zeros_like(e.embeddings.weight)
+        defer = use_sink and self.defer_word_grad
+        dword = None if defer else (sink if use_sink else torch.zeros_like(e.embeddings.weight))
         # text rows
         dz_t, dg_t, db_t = f32(BT, H), f32(H), f32(H)
         ops.ln_bwd(dy, sv["z_t"], sv["mean_t"], sv["rstd_t"], ge, dz_t, None, None, dg_t, db_t, None, ws, BT, H, group=T,
                    out_stride=S, out_off=V, p_post=p_hid, seed=seed(3), row_pre=sv["rm_txt"])
-        ops.embed_scatter_add(sv["ids"], dz_t, dword, BT, H, int(c.pad_index))
+        if defer:
+            self._push_word_grad(sv["ids"].view(-1), dz_t, int(c.pad_index))
+        else:
+            ops.embed_scatter_add(sv["ids"], dz_t, dword, BT, H, int(c.pad_index))
         dpos[V:V + T] += dz_t.view(B, T, H).sum(0)
         # image rows
         dz2, dg_2, db_2 = f32(BV, H), f32(H), f32(H)

@@ -150,6 +150,7 @@ int vl_addmask(const int64_t* text_mask, const int64_t* img_mask, float* addmask
  * UC2Embeddings pieces (embeddings.py:636-669).
  * text: z[b*T+t,:] = word[ids] + pos[cumsum(ids!=pad)*(ids!=pad)+pad] + type[seg]   (RoBERTa position ids,
  *       embeddings.py:157-170); backward scatter-adds dz into the dense tables with float atomics.
+ *       dword may be NULL (the word-table scatter is then done elsewhere, e.g. after a sparse multi-GPU exchange).
  * loc : y[r,:] = loc[r,0:L] . Wl[:,0:L]^T + bl  (L = num_locs <= 8) and its backward.
  * ------------------------------------------------------------------------------------------------------------ */
 int vl_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,

@@ -37,8 +37,19 @@ def _worker(rank, world, port, q):
     local = [p.grad.clone() for _, p, _, _ in groups]
     arena.gather_grads()
     assert all(p.grad is None for _, p, _, _ in groups)
-    post = GradReducer(bucket_bytes=256).allreduce_(arena.grad)  # tiny buckets -> several collectives
+    red = GradReducer(bucket_bytes=256)  # tiny buckets -> several collectives
+    post = red.allreduce_(arena.grad)
     assert post == 1.0 / world
+    # sparse exchange of embedding rows: duplicates inside a rank, overlaps across ranks, and a skipped dense range
+    gen = torch.Generator().manual_seed(7 + rank)
+    ids = torch.randint(0, 13, (10,), generator=gen)
+    rows = torch.randn(10, 4, generator=gen)
+    table = torch.zeros(13, 4)
+    red.exchange_sparse_rows(ids, rows, table,
+                             lambda i, r, t: t.index_add_(0, i[i >= 0], r[i >= 0]))
+    dense = torch.arange(20, dtype=torch.float32) * (rank + 1)
+    red.allreduce_(dense, skip=(4, 12))
+    q.put(("sparse", rank, ids.tolist(), rows.tolist(), table.tolist(), dense.tolist()))
     gathered = [torch.zeros_like(arena.grad) for _ in range(world)]
     q.put((rank, [g.tolist() for g in local], arena.grad.tolist(), arena.offsets))
     dist.barrier()
@@ -52,7 +63,19 @@ def test_flat_arena_allreduce_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)])
+    got = [q.get(timeout=120) for _ in range(2 * world)]
+    sparse = sorted([g for g in got if g[0] == "sparse"])
+    res = sorted([g for g in got if g[0] != "sparse"])
+    ref = torch.zeros(13, 4)
+    for _, _, ids, rows, _, _ in sparse:
+        ref.index_add_(0, torch.tensor(ids), torch.tensor(rows))
+    for _, rank, _, _, table, dense in sparse:
+        torch.testing.assert_close(torch.tensor(table), ref, rtol=1e-6, atol=1e-6)
+        d = torch.tensor(dense)
+        base = torch.arange(20, dtype=torch.float32)
+        assert torch.equal(d[4:12], base[4:12] * (rank + 1))          # skipped range untouched
+        assert torch.equal(d[:4], base[:4] * 3) and torch.equal(d[12:], base[12:] * 3)
+    assert sparse[0][4] == sparse[1][4]                                # bit-identical on both ranks
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
