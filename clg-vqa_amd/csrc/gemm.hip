@@ -46,6 +46,7 @@ struct GemmArgs {
   bf16_raw* out_hi; bf16_raw* out_lo; bf16_raw* aux16; long ld16;
   int tiles_m, tiles_n;
   int alias_rows;               // debug / timing experiment (0 = off)
+  int vec8;                     // 1: additionally 16-byte bf16 epilogue accesses are legal (ld16 % 8 == 0, 16-B pointers)
   int vec;                      // 1: leading dimensions / pointers allow the 16-byte (fp32) / 8-byte (bf16) epilogue
   int splits;                   // TN kernel: number of K-ranges (1-D grid over splits x tiles)
   int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
@@ -133,6 +134,61 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
   }
 }
 
+// 8 consecutive output columns n0..n0+7 of row m (16-bit epilogues of the fast path: two paired MFMA tiles hold the two
+// halves, see the B-row permutation in gemm2_kernel): one 16-byte access per bf16 array instead of two 8-byte ones.
+__device__ __forceinline__ uint4 pack8(const ushort4& a, const ushort4& b) {
+  return make_uint4((unsigned)a.x | ((unsigned)a.y << 16), (unsigned)a.z | ((unsigned)a.w << 16),
+                    (unsigned)b.x | ((unsigned)b.y << 16), (unsigned)b.z | ((unsigned)b.w << 16));
+}
+template <int EPI>
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32, int m, int n0, f32x4 v0, f32x4 v1) {
+  if (!(p.vec8 && n0 + 7 < p.N)) {
+    epilogue_store4<EPI>(p, out32, m, n0, v0);
+    if (n0 + 4 < p.N) epilogue_store4<EPI>(p, out32, m, n0 + 4, v1);
+    return;
+  }
+  float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  if (p.bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
+    x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w; x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
+  }
+  const long o = (long)m * p.ld16 + n0;
+  ushort4 h0, h1, l0, l1;
+  if (EPI == VL_EPI_GELU_SPLIT) {
+    ushort4 u0, u1;
+    u0.x = f32_to_bf16(x[0]); u0.y = f32_to_bf16(x[1]); u0.z = f32_to_bf16(x[2]); u0.w = f32_to_bf16(x[3]);
+    u1.x = f32_to_bf16(x[4]); u1.y = f32_to_bf16(x[5]); u1.z = f32_to_bf16(x[6]); u1.w = f32_to_bf16(x[7]);
+    *reinterpret_cast<uint4*>(p.aux16 + o) = pack8(u0, u1);
+    split_bf16(gelu_erf(x[0]), h0.x, l0.x); split_bf16(gelu_erf(x[1]), h0.y, l0.y);
+    split_bf16(gelu_erf(x[2]), h0.z, l0.z); split_bf16(gelu_erf(x[3]), h0.w, l0.w);
+    split_bf16(gelu_erf(x[4]), h1.x, l1.x); split_bf16(gelu_erf(x[5]), h1.y, l1.y);
+    split_bf16(gelu_erf(x[6]), h1.z, l1.z); split_bf16(gelu_erf(x[7]), h1.w, l1.w);
+    *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
+    *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
+  } else if (EPI == VL_EPI_DGELU_BF16) {
+    const uint4 uu = *reinterpret_cast<const uint4*>(p.aux16 + o);
+    const unsigned w[4] = {uu.x, uu.y, uu.z, uu.w};
+    bf16_raw r[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      r[2 * t] = f32_to_bf16(x[2 * t] * gelu_erf_grad(bf16_to_f32((bf16_raw)(w[t] & 0xFFFFu))));
+      r[2 * t + 1] = f32_to_bf16(x[2 * t + 1] * gelu_erf_grad(bf16_to_f32((bf16_raw)(w[t] >> 16))));
+    }
+    h0.x = r[0]; h0.y = r[1]; h0.z = r[2]; h0.w = r[3]; h1.x = r[4]; h1.y = r[5]; h1.z = r[6]; h1.w = r[7];
+    *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
+  } else if (EPI == VL_EPI_BF16) {
+    h0.x = f32_to_bf16(x[0]); h0.y = f32_to_bf16(x[1]); h0.z = f32_to_bf16(x[2]); h0.w = f32_to_bf16(x[3]);
+    h1.x = f32_to_bf16(x[4]); h1.y = f32_to_bf16(x[5]); h1.z = f32_to_bf16(x[6]); h1.w = f32_to_bf16(x[7]);
+    *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
+  } else {  // VL_EPI_SPLIT
+    split_bf16(x[0], h0.x, l0.x); split_bf16(x[1], h0.y, l0.y); split_bf16(x[2], h0.z, l0.z); split_bf16(x[3], h0.w, l0.w);
+    split_bf16(x[4], h1.x, l1.x); split_bf16(x[5], h1.y, l1.y); split_bf16(x[6], h1.z, l1.z); split_bf16(x[7], h1.w, l1.w);
+    *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
+    *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // fast path: 256 x BN tile, LDS-DMA staging, double-buffered
 // ---------------------------------------------------------------------------------------------------------------
@@ -148,6 +204,12 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
   constexpr int UPW = (UNITS + NWAVES - 1) / NWAVES;       // units per wave
   constexpr int STAGE = UNITS * 1024;
   constexpr int KSTEP = NSPLIT == 3 ? 32 : 64;             // k elements consumed per stage
+  // 16-bit epilogues: n-tiles are processed in PAIRS whose 16 MFMA columns interleave in groups of 4, so that a lane's
+  // accumulators of tiles (2t, 2t+1) are 8 consecutive output columns (one 16-byte bf16 store).  This is a pure
+  // permutation of which B row feeds which MFMA column; the B tile then uses its own bank swizzle fB (the permuted
+  // fragment reads touch rows {0-3, 8-11, 16-19, 24-27} (+4) instead of 16 consecutive ones).
+  constexpr bool PAIR = (EPI != VL_EPI_F32);
+  constexpr int NTP = PAIR ? (NT & ~1) : 0;                // tiles [0, NTP) are paired
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -176,7 +238,9 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
     const int lim = (isB ? p.N : p.M) - 1;
     grow = grow < lim ? grow : lim;  // rows past the edge re-read the last row; their products are never stored
     if (!isB && p.alias_rows) grow %= p.alias_rows;
-    const int lc = (lane & 7) ^ ((trow >> 1) & 7);  // logical 16-B chunk that lands at physical position lane&7
+    const int fsw = (PAIR && isB) ? (((0x78 >> (2 * ((trow >> 3) & 3))) & 3) | (((trow >> 1) & 1) << 2))
+                                  : ((trow >> 1) & 7);
+    const int lc = (lane & 7) ^ fsw;  // logical 16-B chunk that lands at physical position lane&7
     const bf16_raw* base;
     int koff;
     if (NSPLIT == 3) {
@@ -213,9 +277,9 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
   }
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int row = wn * (BN / 4) + j * 16 + frow;
+    const int row = wn * (BN / 4) + (j < NTP ? 32 * (j >> 1) + 8 * (frow >> 2) + 4 * (j & 1) + (frow & 3) : j * 16 + frow);
     b_off[j] = A_UNITS * 1024 + row * 128;
-    b_sw[j] = (row >> 1) & 7;
+    b_sw[j] = PAIR ? (((0x78 >> (2 * ((row >> 3) & 3))) & 3) | (((row >> 1) & 1) << 2)) : ((row >> 1) & 7);
   }
 
   issue(0, 0);
@@ -267,8 +331,14 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
     if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n0 = col0 + wn * (BN / 4) + j * 16 + 4 * (lane >> 4);
-      if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[i][j]);
+      if (j < NTP) {
+        if (j & 1) continue;
+        const int n0 = col0 + wn * (BN / 4) + 32 * (j >> 1) + 8 * (lane >> 4);
+        if (n0 < p.N) epilogue_store8<EPI>(p, out32, m, n0, acc[i][j], acc[i][j + 1 < NT ? j + 1 : j]);
+      } else {
+        const int n0 = col0 + wn * (BN / 4) + j * 16 + 4 * (lane >> 4);
+        if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[i][j]);
+      }
     }
   }
 }
@@ -633,6 +703,7 @@ extern "C" int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const
   a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.aux16 = (bf16_raw*)aux16; a.ld16 = ld16;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   a.k_len = (int)K; a.slab_stride = 0;
+  a.vec8 = (ld16 & 7) == 0 && aligned16(bias) && aligned16(out_hi) && aligned16(out_lo) && aligned16(aux16);
   a.vec = ((ldc | ld16) & 3) == 0 && aligned16(bias) && aligned16(resid32) && aligned16(out32) &&
           ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo) |
             reinterpret_cast<uintptr_t>(aux16)) & 7) == 0;

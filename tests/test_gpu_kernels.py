@@ -97,8 +97,8 @@ def test_gemm_tn_splitk(M, N, K):
     assert not ops.gemm_tn_splitk(a[:, :64].contiguous(), b, 64, N, K, out[:64].contiguous())  # outside the fast path
 
 
-def test_gemm_epilogues():
-    M, N, K = 384, 512, 256
+@pytest.mark.parametrize("M,N,K", [(384, 512, 256), (300, 200, 128), (512, 3072, 768), (260, 776, 64), (100, 72, 64)])
+def test_gemm_epilogues(M, N, K):
     x, w, bias = _rand(M, K, seed=9), _rand(N, K, seed=10, scale=0.1), _rand(N, seed=11)
     xh, xl = _split(x)
     wh, wl = _split(w)
