@@ -136,6 +136,10 @@ class LayerStack(object):
 
     def __init__(self, specs, H, nh, I, eps):
         self.specs, self.H, self.nh, self.I, self.eps = specs, H, nh, I, eps
+        # weight-gradient GEMMs (dW = dY^T X, bias column sums) are off the backward critical path: they run on a
+        # second HIP stream so that their workgroups fill the CUs the dX / LayerNorm / attention kernels leave idle
+        self.overlap_dw = True
+        self._side = None
 
     def make_prepared(self, device):
         return [dict(qkv=PreparedWeight([sp.q, sp.k, sp.v], device), o=PreparedWeight([sp.o], device),
@@ -178,6 +182,25 @@ class LayerStack(object):
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
         layer_grads = [None] * len(self.specs)
+        main = torch.cuda.current_stream()
+        side = None
+        if self.overlap_dw:
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            side = self._side
+        keep = []  # operands of side-stream kernels stay referenced until the streams are joined
+
+        def on_side(fn, *tensors):
+            """Run fn (weight-gradient work) on the side stream after everything enqueued so far on the main one."""
+            if side is None:
+                return fn()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            keep.extend(tensors)
+            with torch.cuda.stream(side):
+                return fn()
+
         for l in reversed(range(len(self.specs))):
             sp, lw, ls = self.specs[l], pw_layers[l], saved[l]
             dz2, dt2 = f32(M, H), b16(M, H)
@@ -186,31 +209,39 @@ class LayerStack(object):
                        ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
             du16 = b16(M, I)
             ops.gemm_nt(dt2, None, lw["w2"].t_hi, None, M, I, H, 1, EPI_DGELU_BF16, out_hi=du16, aux16=ls["u16"])
+            dW2, dW1, dbias1 = on_side(lambda: (_masked(dw_gemm(dt2, ls["h_hi"], M, H, I), sp.w2),
+                                                _masked(dw_gemm(du16, ls["x1_hi"], M, I, H), sp.w1),
+                                                ops.colsum_bf16(du16, M, I, f32(I))),
+                                       dt2, du16, ls["h_hi"], ls["x1_hi"])
             dx1 = f32(M, H)
             ops.gemm_nt(du16, None, lw["w1"].t_hi, None, M, H, I, 1, EPI_F32, resid=dz2, out32=dx1)
-            dW2 = _masked(dw_gemm(dt2, ls["h_hi"], M, H, I), sp.w2)
-            dW1 = _masked(dw_gemm(du16, ls["x1_hi"], M, I, H), sp.w1)
-            dbias1 = ops.colsum_bf16(du16, M, I, f32(I))
             dz1, dt1 = f32(M, H), b16(M, H)
             dg1, db1, dbias_o = f32(H), f32(H), f32(H)
             ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, dg1, db1,
                        dbias_o, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
+            dWo = on_side(lambda: _masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), sp.o), dt1, ls["ctx_hi"])
             dctx = f32(M, H)
             ops.gemm_nt(dt1, None, lw["o"].t_hi, None, M, H, H, 1, EPI_F32, out32=dctx)
-            dWo = _masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), sp.o)
             dqkv = b16(M, 3 * H)
             ops.attn_bwd(ls["qkv32"], am, ls["ctx_hi"], ls["ctx_lo"], dctx, ls["lse"], dqkv, B, S, nh, 64, p_att,
                          seed(16 * l + 3))
+
+            def qkv_grads():
+                dW = dw_gemm(dqkv, ls["x_hi"], M, 3 * H, H)
+                for i, lin in enumerate((sp.q, sp.k, sp.v)):
+                    _masked(dW[i * H:(i + 1) * H], lin)
+                return dW, ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H))
+
+            dWqkv, dbqkv = on_side(qkv_grads, dqkv, ls["x_hi"])
             dx0 = f32(M, H)
             ops.gemm_nt(dqkv, None, lw["qkv"].t_hi, None, M, H, 3 * H, 1, EPI_F32, resid=dz1, out32=dx0)
-            dWqkv = dw_gemm(dqkv, ls["x_hi"], M, 3 * H, H)
-            for i, lin in enumerate((sp.q, sp.k, sp.v)):
-                _masked(dWqkv[i * H:(i + 1) * H], lin)
-            dbqkv = ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H))
             layer_grads[l] = [dWqkv[0:H], dbqkv[0:H], dWqkv[H:2 * H], dbqkv[H:2 * H], dWqkv[2 * H:], dbqkv[2 * H:],
                               dWo, dbias_o, dg1, db1, dW1, dbias1, dW2, dbias2, dg2, db2]
             dy = dx0
-            saved[l] = None  # release this layer's activations
+            saved[l] = None  # release this layer's activations (side-stream operands stay alive through `keep`)
+        if side is not None:
+            main.wait_stream(side)
+        del keep
         return dy, layer_grads
 
 
