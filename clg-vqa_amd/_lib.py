@@ -41,13 +41,13 @@ _SIGS = {
     "vl_colsum_bf16": (c_int, [P, c_int64, c_int64, c_int64, P, P, P]),
     "vl_addmask": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_embed_text_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
-    "vl_embed_text_bwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
+    "vl_embed_text_bwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P, P]),
     "vl_embed_gather_fwd": (c_int, [P, P, P, c_int64, c_int64, P]),
-    "vl_embed_scatter_add": (c_int, [P, P, P, c_int64, c_int64, c_int64, P]),
+    "vl_embed_scatter_add": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P]),
     "vl_loc_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_loc_linear_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_adamw": (c_int, [P, P, P, P, c_int64, P, P, P, c_int64, c_float, c_float, c_float, c_int64, c_int, c_float,
-                         P, c_float, c_int, P]),
+                         P, c_float, c_int, P, c_int64, c_int64, c_int64, P]),
     "vl_sumsq": (c_int, [P, c_int64, P, P]),
 }
 

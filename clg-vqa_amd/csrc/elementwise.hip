@@ -202,7 +202,8 @@ __global__ __launch_bounds__(256) void embed_text_fwd_kernel(const int64_t* __re
 __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const int64_t* __restrict__ ids,
                                                              const int64_t* __restrict__ seg,
                                                              const float* __restrict__ dz, float* dword, float* dpos,
-                                                             float* dtype, int B, int T, int H, int64_t pad) {
+                                                             float* dtype, int B, int T, int H, int64_t pad,
+                                                             unsigned char* row_flags) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long r = (long)blockIdx.x * 4 + wave;
   if (r >= (long)B * T) return;
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256) void embed_text_bwd_kernel(const int64_t* __re
   float* wr = dword + id * (long)H;
   float* pr = dpos + (long)pid * H;
   float* tr = dtype + seg[r] * (long)H;
+  if (row_flags && dword && id != pad && lane == 0) row_flags[id] = 1;  // this table row now carries optimizer state
   for (int c = lane; c < H; c += 64) {
     const float g = dz[r * H + c];
     if (dword && id != pad) atomicAdd(wr + c, g);
@@ -231,12 +233,14 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const int64_t* __restr
     *reinterpret_cast<float4*>(out + r * H + c) = *reinterpret_cast<const float4*>(src + c);
 }
 __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dz,
-                                                           float* dtab, long R, int H, int64_t pad) {
+                                                           float* dtab, long R, int H, int64_t pad,
+                                                           unsigned char* row_flags) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long r = (long)blockIdx.x * 4 + wave;
   if (r >= R) return;
   const int64_t id = ids[r];
-  if (id == pad) return;  // nn.Embedding(padding_idx): the pad row receives no gradient
+  if (id == pad || id < 0) return;  // nn.Embedding(padding_idx): the pad row receives no gradient; -1 = empty slot
+  if (row_flags && lane == 0) row_flags[id] = 1;
   float* dst = dtab + id * (long)H;
   for (int c = lane; c < H; c += 64) atomicAdd(dst + c, dz[r * H + c]);
 }
@@ -284,7 +288,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     const float* __restrict__ seg_lr,
                                                     const float* __restrict__ seg_wd, int nseg, float b1, float b2,
                                                     float eps, float bc, float lr_mult, const float* gscale_ptr,
-                                                    float gscale_const, int zero_grad) {
+                                                    float gscale_const, int zero_grad,
+                                                    const unsigned char* __restrict__ row_flags, long fl_beg4, long fl_end4,
+                                                    int fl_row4) {
   // segment table (every segment starts on a multiple of 4 elements) -> LDS, in float4 units
   __shared__ int s_end4[ADAMW_MAX_SEG];
   __shared__ float s_lr[ADAMW_MAX_SEG], s_wd[ADAMW_MAX_SEG];
@@ -304,6 +310,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
       if (s_end4[mid] > i) hi = mid; else lo = mid + 1;
     }
     const float lr = s_lr[lo], wd = s_wd[lo], step = lr * bc, decay = 1.f - lr * wd;
+    if (row_flags && i >= fl_beg4 && i < fl_end4 && !row_flags[(i - fl_beg4) / fl_row4]) {
+      // embedding row that never received a gradient: g = m = v = 0, so the AdamW update is exactly p *= decay
+      // (m, v, g stay 0).  Touch 8 B/param instead of 32 B/param -- bit-identical to the dense path.
+      if (wd > 0.f && lr != 0.f) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        pp.x *= decay; pp.y *= decay; pp.z *= decay; pp.w *= decay;
+        reinterpret_cast<float4*>(p)[i] = pp;
+      }
+      continue;
+    }
     float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
 #define VL_ADAM1(c)                                          \
@@ -437,10 +453,11 @@ extern "C" int vl_embed_text_fwd(const int64_t* ids, const int64_t* seg, const f
   return 0;
 }
 extern "C" int vl_embed_text_bwd(const int64_t* ids, const int64_t* seg, const float* dz32, float* dword, float* dpos,
-                                 float* dtype, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream) {
+                                 float* dtype, int64_t B, int64_t T, int64_t H, int64_t pad_id, uint8_t* row_flags,
+                                 void* stream) {
   VL_CHECK_ARG(ids && seg && dz32 && dpos && dtype && B > 0 && T > 0 && H > 0, "vl_embed_text_bwd: bad arguments");
   hipLaunchKernelGGL(embed_text_bwd_kernel, dim3((unsigned)((B * T + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids,
-                     seg, dz32, dword, dpos, dtype, (int)B, (int)T, (int)H, pad_id);
+                     seg, dz32, dword, dpos, dtype, (int)B, (int)T, (int)H, pad_id, row_flags);
   VL_CHECK_LAUNCH("vl_embed_text_bwd");
   return 0;
 }
@@ -454,10 +471,10 @@ extern "C" int vl_embed_gather_fwd(const int64_t* ids, const float* table, float
   return 0;
 }
 extern "C" int vl_embed_scatter_add(const int64_t* ids, const float* dz32, float* dtable, int64_t R, int64_t H,
-                                    int64_t pad_id, void* stream) {
+                                    int64_t pad_id, uint8_t* row_flags, void* stream) {
   VL_CHECK_ARG(ids && dz32 && dtable && R > 0 && H > 0, "vl_embed_scatter_add: bad arguments");
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ids, dz32,
-                     dtable, (long)R, (int)H, pad_id);
+                     dtable, (long)R, (int)H, pad_id, row_flags);
   VL_CHECK_LAUNCH("vl_embed_scatter_add");
   return 0;
 }
@@ -482,18 +499,23 @@ extern "C" int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw,
 extern "C" int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1,
                         float beta2, float eps, int64_t step, int correct_bias, float lr_mult,
-                        const float* grad_scale_dev, float grad_scale, int zero_grad, void* stream) {
+                        const float* grad_scale_dev, float grad_scale, int zero_grad, const uint8_t* row_flags,
+                        int64_t flag_begin, int64_t flag_rows, int64_t flag_row_len, void* stream) {
   VL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && seg_end && seg_lr && seg_wd && n > 0 && nseg > 0 && step > 0,
                "vl_adamw: bad arguments");
   VL_CHECK_ARG(nseg <= ADAMW_MAX_SEG && (n & 3) == 0 && (n >> 2) < (1LL << 31),
                "vl_adamw: arena length must be a multiple of 4 (segments 4-aligned), nseg <= %d", ADAMW_MAX_SEG);
   VL_CHECK_ARG((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                "vl_adamw: arenas must be 16-byte aligned");
+  VL_CHECK_ARG(!row_flags || (flag_begin % 4 == 0 && flag_row_len % 4 == 0 && flag_row_len > 0 && flag_rows > 0 &&
+                              flag_begin + flag_rows * flag_row_len <= n),
+               "vl_adamw: flagged segment must be 4-aligned and inside the arena");
   float bc = 1.0f;
   if (correct_bias) bc = (float)(sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step)));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, param, grad,
                      exp_avg, exp_avg_sq, (long)(n / 4), seg_end, seg_lr, seg_wd, (int)nseg, beta1, beta2, eps, bc, lr_mult,
-                     grad_scale_dev, grad_scale, zero_grad);
+                     grad_scale_dev, grad_scale, zero_grad, row_flags, (long)(flag_begin / 4),
+                     (long)((flag_begin + flag_rows * flag_row_len) / 4), (int)(flag_row_len / 4));
   VL_CHECK_LAUNCH("vl_adamw");
   return 0;
 }

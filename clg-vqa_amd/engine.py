@@ -259,6 +259,7 @@ class EngineBase(object):
         # into directly (FusedAdamW installs a view of its flat gradient arena; the arena is re-zeroed by the
         # optimizer kernel).  Saves the 768 MB zero-fill and the 768 MB copy per step of the dense path.
         self.word_grad_sink = None
+        self.word_row_flags = None  # uint8 [vocab]: rows that ever received a gradient (owned by the optimizer)
         # multi-GPU: instead of scattering, hand (token ids, gradient rows) to the reducer, which exchanges the
         # <= B*T touched rows sparsely (all-gather) instead of all-reducing the dense 768 MB table gradient
         self.defer_word_grad = False
@@ -443,7 +444,8 @@ class UC2Engine(EngineBase):
         dz_t, dg_e, db_e = f32(BT, H), f32(H), f32(H)
         ops.ln_bwd(dy, sv["z_t"], sv["mean_t"], sv["rstd_t"], emb.LayerNorm.weight.detach(), dz_t, None, None, dg_e,
                    db_e, None, ws, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
-        ops.embed_text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id))
+        ops.embed_text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id),
+                           row_flags=self.word_row_flags if use_sink else None)
         if defer:
             self._push_word_grad(sv["ids"].view(-1), dz_t, int(cfg.pad_token_id))
         dtype_[1] += dtype1  # image_token_type_embeddings is new_token_type_embeddings (embeddings.py:628)

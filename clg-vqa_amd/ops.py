@@ -174,17 +174,17 @@ def embed_text_fwd(ids, seg, word, pos, typ, z32, B, T, H, pad_id):
                                             _stream()), "vl_embed_text_fwd")
 
 
-def embed_text_bwd(ids, seg, dz32, dword, dpos, dtyp, B, T, H, pad_id):
+def embed_text_bwd(ids, seg, dz32, dword, dpos, dtyp, B, T, H, pad_id, row_flags=None):
     _lib.check(_lib.lib().vl_embed_text_bwd(_p(ids), _p(seg), _p(dz32), _p(dword), _p(dpos), _p(dtyp), B, T, H,
-                                            pad_id, _stream()), "vl_embed_text_bwd")
+                                            pad_id, _p(row_flags), _stream()), "vl_embed_text_bwd")
 
 
 def embed_gather_fwd(ids, table, out32, R, H):
     _lib.check(_lib.lib().vl_embed_gather_fwd(_p(ids), _p(table), _p(out32), R, H, _stream()), "vl_embed_gather_fwd")
 
 
-def embed_scatter_add(ids, dz32, dtable, R, H, pad_id=-1):
-    _lib.check(_lib.lib().vl_embed_scatter_add(_p(ids), _p(dz32), _p(dtable), R, H, pad_id, _stream()),
+def embed_scatter_add(ids, dz32, dtable, R, H, pad_id=-1, row_flags=None):
+    _lib.check(_lib.lib().vl_embed_scatter_add(_p(ids), _p(dz32), _p(dtable), R, H, pad_id, _p(row_flags), _stream()),
                "vl_embed_scatter_add")
 
 
@@ -198,11 +198,13 @@ def loc_linear_bwd(loc, dy32, dw, db, R, L, H):
 
 
 def adamw(param, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, seg_wd, beta1, beta2, eps, step, correct_bias, lr_mult,
-          grad_scale_dev=None, grad_scale=1.0, zero_grad=False):
+          grad_scale_dev=None, grad_scale=1.0, zero_grad=False, row_flags=None, flag_begin=0, flag_rows=0,
+          flag_row_len=0):
     _lib.check(_lib.lib().vl_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(seg_end),
                                    _p(seg_lr), _p(seg_wd), seg_end.numel(), float(beta1), float(beta2), float(eps),
                                    int(step), int(bool(correct_bias)), float(lr_mult), _p(grad_scale_dev),
-                                   float(grad_scale), int(bool(zero_grad)), _stream()), "vl_adamw")
+                                   float(grad_scale), int(bool(zero_grad)), _p(row_flags), flag_begin, flag_rows,
+                                   flag_row_len, _stream()), "vl_adamw")
 
 
 def sumsq(x, out):

@@ -162,7 +162,7 @@ class FusedAdamW(object):
         self._scale = torch.zeros(1, dtype=torch.float32, device=device)
         if hasattr(model, "mark_weights_dirty"):
             model.mark_weights_dirty()
-        self._active, self._sink_index = None, -1
+        self._active, self._sink_index, self.row_flags = None, -1, None
         eng = getattr(model, "engine", None)
         if eng is not None:  # scatter the word-embedding gradient straight into the (zeroed) arena
             emb = model.bert.embeddings.word_embeddings if hasattr(model.bert, "embeddings") else model.bert.encoder.embeddings
@@ -170,22 +170,37 @@ class FusedAdamW(object):
                 if p is emb.weight:
                     eng.word_grad_sink = gv
                     self._sink_index = i
+                    # rows of the table that ever received a gradient; all others keep m = v = 0 and only decay
+                    self.row_flags = torch.zeros(p.shape[0], dtype=torch.uint8, device=device)
+                    eng.word_row_flags = self.row_flags
             eng.defer_word_grad = self.reducer.world_size() > 1
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "opt_step": self.opt_step,
-                "sched_step": self.sched_step, "names": [g[0] for g in self.groups]}
+                "sched_step": self.sched_step, "names": [g[0] for g in self.groups], "row_flags": self.row_flags}
 
     def load_state_dict(self, sd):
         assert sd["names"] == [g[0] for g in self.groups], "optimizer state belongs to a different parameter list"
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.opt_step, self.sched_step = int(sd["opt_step"]), int(sd["sched_step"])
+        if self.row_flags is not None:
+            if sd.get("row_flags") is not None:
+                self.row_flags.copy_(sd["row_flags"])
+            else:
+                self.row_flags.fill_(1)  # unknown history: treat every row as touched (dense update)
 
     def zero_grad(self):
         self.arena.grad.zero_()
         for _, p, _, _ in self.groups:
             p.grad = None
+
+    def _flag_args(self):
+        if self.row_flags is None:
+            return {}
+        gv = self.arena.grad_views[self._sink_index]
+        return dict(row_flags=self.row_flags, flag_begin=self.arena.offsets[self._sink_index], flag_rows=gv.shape[0],
+                    flag_row_len=gv.shape[1])
 
     def lr_mult(self):
         if self.t_total is None:
@@ -211,7 +226,8 @@ class FusedAdamW(object):
             gv = a.grad_views[self._sink_index]
             H = gv.shape[1]
             self.reducer.exchange_sparse_rows(
-                ids, rows, gv, lambda i, r, t: ops.embed_scatter_add(i.contiguous(), r.contiguous(), t, i.numel(), H, -1))
+                ids, rows, gv, lambda i, r, t: ops.embed_scatter_add(i.contiguous(), r.contiguous(), t, i.numel(), H, -1,
+                                                                     row_flags=self.row_flags))
             off = a.offsets[self._sink_index]
             skip = (off, off + (gv.numel() + 3) // 4 * 4)
         post = self.reducer.allreduce_(a.grad, skip)
@@ -224,7 +240,7 @@ class FusedAdamW(object):
         self.opt_step += 1
         ops.adamw(a.param, a.grad, self.exp_avg, self.exp_avg_sq, self.seg_end, self.seg_lr, self.seg_wd,
                   self.betas[0], self.betas[1], self.eps, self.opt_step, self.correct_bias, self.lr_mult(),
-                  grad_scale_dev=self._scale, zero_grad=True)
+                  grad_scale_dev=self._scale, zero_grad=True, **self._flag_args())
         self.sched_step += 1
         if hasattr(self.model, "mark_weights_dirty"):
             self.model.mark_weights_dirty()

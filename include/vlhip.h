@@ -156,12 +156,14 @@ int vl_addmask(const int64_t* text_mask, const int64_t* img_mask, float* addmask
 int vl_embed_text_fwd(const int64_t* ids, const int64_t* seg, const float* word, const float* pos,
                       const float* type, float* z32, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream);
 int vl_embed_text_bwd(const int64_t* ids, const int64_t* seg, const float* dz32, float* dword, float* dpos,
-                      float* dtype, int64_t B, int64_t T, int64_t H, int64_t pad_id, void* stream);
+                      float* dtype, int64_t B, int64_t T, int64_t H, int64_t pad_id, uint8_t* row_flags, void* stream);
 /* plain row gather out[r,:] = table[ids[r],:] and its scatter-add (atomics; rows with ids[r] == pad_id skipped; pass
  * pad_id = -1 for none) -- M3P's text embedding `self.embeddings(x)` (m3p_transformer.py:908). */
 int vl_embed_gather_fwd(const int64_t* ids, const float* table, float* out32, int64_t R, int64_t H, void* stream);
 int vl_embed_scatter_add(const int64_t* ids, const float* dz32, float* dtable, int64_t R, int64_t H, int64_t pad_id,
-                         void* stream);
+                         uint8_t* row_flags, void* stream);
+/* row_flags (optional, [table rows] bytes): set to 1 for every row that receives a gradient; vl_adamw uses it to
+ * skip the optimizer state of embedding rows that were never touched (exactly: their update is p *= 1 - lr*wd). */
 int vl_loc_linear_fwd(const float* loc, const float* w, const float* b, float* y32, int64_t R, int64_t L, int64_t H,
                       void* stream);
 /* dw [H,L], db [H] are ACCUMULATED with atomics: zero them first. */
@@ -176,11 +178,15 @@ int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db,
  * segment i in the arena, seg_lr / seg_wd its base lr and weight decay (215 one-tensor param groups,
  * train_task.py:249-260); `lr_mult` = the LR schedule's multiplier for this step (WarmupLinearSchedule,
  * train_task.py:274).  `step` = 1-based optimizer step.  Also zeroes the gradient when zero_grad != 0.
+ * row_flags (may be NULL): per-row "has ever received a gradient" bytes for the table occupying arena elements
+ * [flag_begin, flag_begin + flag_rows*flag_row_len): rows with flag 0 have g = m = v = 0, so only p *= (1 - lr*wd)
+ * is applied (8 B/param of traffic instead of 32; bit-identical to the dense update).
  * ------------------------------------------------------------------------------------------------------------ */
 int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const int64_t* seg_end,
              const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1, float beta2, float eps,
              int64_t step, int correct_bias, float lr_mult, const float* grad_scale_dev, float grad_scale,
-             int zero_grad, void* stream);
+             int zero_grad, const uint8_t* row_flags, int64_t flag_begin, int64_t flag_rows, int64_t flag_row_len,
+             void* stream);
 /* out[0] += sum(x^2) over n floats (atomic; zero out[0] first). */
 int vl_sumsq(const float* x, int64_t n, float* out, void* stream);
 

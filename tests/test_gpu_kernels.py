@@ -377,3 +377,27 @@ def test_adamw_and_sumsq():
     out = torch.zeros(1, device=DEV)
     ops.sumsq(g, out)
     torch.testing.assert_close(out.double().cpu(), (g0 * g0).sum().view(1), rtol=1e-5, atol=1e-5)
+
+
+def test_adamw_untouched_row_fast_path_is_bit_identical():
+    rows, H, extra = 50, 64, 40
+    n = rows * H + extra
+    p0 = _rand(n, seed=50)
+    g = _rand(n, seed=51)
+    touched = torch.zeros(rows, dtype=torch.uint8, device=DEV)
+    touched[[3, 17, 18, 49]] = 1
+    gt = g[:rows * H].view(rows, H)
+    gt[touched == 0] = 0  # untouched rows have no gradient
+    seg_end = torch.tensor([rows * H, n], dtype=torch.int64, device=DEV)
+    seg_lr = torch.tensor([4e-5, 1e-4], device=DEV)
+    seg_wd = torch.tensor([1e-2, 0.0], device=DEV)
+    res = []
+    for flags in (None, touched):
+        p, gg = p0.clone(), g.clone()
+        m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        for step in (1, 2, 3):
+            kw = {} if flags is None else dict(row_flags=flags, flag_begin=0, flag_rows=rows, flag_row_len=H)
+            ops.adamw(p, gg, m, v, seg_end, seg_lr, seg_wd, 0.9, 0.999, 1e-6, step, True, 1.0, None, 1.0, False, **kw)
+        res.append((p, m, v))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
