@@ -44,55 +44,89 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld
   }
 }
 
+// Forward.  One trip = the 4 waves of the workgroup each take one 16-query tile.
+//  * every global load of the trip (K, V, Q) is issued up front; Q goes straight to registers in MFMA A-operand
+//    order with the head dimension permuted (lane k4 owns d = 16*k4 .. 16*k4+15: one contiguous 64-byte load per lane;
+//    the K operand is read from LDS with the same permutation, so the dot products are unchanged);
+//  * S <= 64 (a single trip): K and V time-share ONE LDS buffer (V waits in registers while Q.K^T runs), which
+//    brings the workgroup to ~35 KB of LDS -> 4 workgroups per CU instead of 2;
+//  * K/V rows are padded to 65 floats: the permuted operand reads (row = lane&15, col = 16*k4 + step) hit 32
+//    distinct banks.
+constexpr int LDK = 65;
+
+__device__ __forceinline__ void store_row4(float* dst, const float4& v) {  // rows are only 4-byte aligned (LDK odd)
+  dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   extern __shared__ __attribute__((aligned(16))) float smf[];
   constexpr int Spad = NT * 16, LDP = Spad + 2;
+  constexpr bool SHARE = NT <= 4;        // single trip: K and V share one buffer
+  constexpr int NLD = (Spad * 16 + 255) / 256;  // float4 loads per thread to stage one [Spad][64] matrix
   float* sK = smf;
-  float* sV = sK + Spad * LDT;
-  float* smask = sV + Spad * LDT;
-  float* wbase = smask + Spad;
+  float* sV = SHARE ? sK : sK + Spad * LDK;
+  float* smask = sV + Spad * LDK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float* sQ = wbase + wave * (16 * LDT + 16 * LDP);
-  float* sP = sQ + 16 * LDT;
+  float* sP = smask + Spad + wave * (16 * LDP);
 
   const int b = blockIdx.x / p.nh, h = blockIdx.x - b * p.nh;
   const int S = p.S;
   const long ld = 3L * p.H;
   const float* base = p.qkv + (long)b * S * ld + h * DH;
-  stage_rows(sK, base + p.H, ld, S, Spad, tid);
-  stage_rows(sV, base + 2 * p.H, ld, S, Spad, tid);
-  for (int k = tid; k < Spad; k += 256) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
-
-  const int nqt = (S + 15) >> 4;
   const int i16 = lane & 15, k4 = lane >> 4;
+
+  // ---- issue all global loads ----
+  float4 rk[NLD], rv[NLD];
+#pragma unroll
+  for (int t = 0; t < NLD; ++t) {
+    const int idx = tid + t * 256, row = idx >> 4, c4 = idx & 15;
+    rk[t] = rv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (idx < Spad * 16 && row < S) {
+      rk[t] = *reinterpret_cast<const float4*>(base + p.H + (long)row * ld + c4 * 4);
+      rv[t] = *reinterpret_cast<const float4*>(base + 2 * p.H + (long)row * ld + c4 * 4);
+    }
+  }
+  const int nqt = (S + 15) >> 4;
+  // this wave's Q tile: lane (i16, k4) holds Q[q][16*k4 .. 16*k4+15]; issued before anything waits on K/V
+  float qa[16];
+  auto load_q = [&](int qt) {
+    const int q = qt * 16 + i16;
+    float4 v4[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v4[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (qt < nqt && q < S) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v4[t] = *reinterpret_cast<const float4*>(base + (long)q * ld + 16 * k4 + 4 * t);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { qa[4 * t] = v4[t].x; qa[4 * t + 1] = v4[t].y; qa[4 * t + 2] = v4[t].z; qa[4 * t + 3] = v4[t].w; }
+  };
+  load_q(wave);
+  for (int k = tid; k < Spad; k += 256) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NLD; ++t) {
+    const int idx = tid + t * 256, row = idx >> 4, c4 = idx & 15;
+    if (idx < Spad * 16) {
+      store_row4(sK + row * LDK + c4 * 4, rk[t]);
+      if (!SHARE) store_row4(sV + row * LDK + c4 * 4, rv[t]);
+    }
+  }
+
   for (int it = 0; it * 4 < nqt; ++it) {
     const int qt = it * 4 + wave;
     const bool active = qt < nqt;
-    // this wave's 16 query rows -> its private LDS tile
-    if (active) {
-      for (int idx = lane; idx < 256; idx += 64) {
-        const int row = idx >> 4, c4 = idx & 15, q = qt * 16 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < S) v = *reinterpret_cast<const float4*>(base + (long)q * ld + c4 * 4);
-        float2* d = reinterpret_cast<float2*>(sQ + row * LDT + c4 * 4);
-        d[0] = make_float2(v.x, v.y);
-        d[1] = make_float2(v.z, v.w);
-      }
-    }
-    __syncthreads();  // K/V/mask (first trip) and this trip's Q tile are visible
+    __syncthreads();  // K (and the mask) are in LDS
     f32x4 sc[NT];
     if (active) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) sc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-      for (int ks = 0; ks < DH / 4; ++ks) {
-        const float a = sQ[i16 * LDT + 4 * ks + k4];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          sc[nt] = mfma4(a, sK[(nt * 16 + i16) * LDT + 4 * ks + k4], sc[nt]);
+          sc[nt] = mfma4(qa[ks], sK[(nt * 16 + i16) * LDK + 16 * k4 + ks], sc[nt]);
       }
-      // softmax over the key axis (columns): each row lives on the 16 lanes sharing lane>>4
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = 4 * k4 + r, q = qt * 16 + ql;
@@ -122,7 +156,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         }
       }
     }
-    __syncthreads();  // P tile written by all lanes of the wave
+    __syncthreads();  // every wave is done with K; P tiles are written
+    if (SHARE) {      // V takes over the K buffer
+#pragma unroll
+      for (int t = 0; t < NLD; ++t) {
+        const int idx = tid + t * 256, row = idx >> 4, c4 = idx & 15;
+        if (idx < Spad * 16) store_row4(sV + row * LDK + c4 * 4, rv[t]);
+      }
+      __syncthreads();
+    }
     if (active) {
       f32x4 o[4];
 #pragma unroll
@@ -131,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       for (int ks = 0; ks < Spad / 4; ++ks) {
         const float a = sP[i16 * LDP + 4 * ks + k4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma4(a, sV[(4 * ks + k4) * LDT + dt * 16 + i16], o[dt]);
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma4(a, sV[(4 * ks + k4) * LDK + dt * 16 + i16], o[dt]);
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -147,7 +189,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
           }
         }
     }
-    __syncthreads();  // before the next trip overwrites sQ / sP
+    if ((it + 1) * 4 < nqt) load_q((it + 1) * 4 + wave);
+    __syncthreads();  // before the next trip overwrites the P tiles (only reached when !SHARE)
   }
 }
 
@@ -284,7 +327,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 
 inline size_t fwd_lds_bytes(int NT) {
   const int Spad = NT * 16, LDP = Spad + 2;
-  return sizeof(float) * (size_t)(2 * Spad * LDT + Spad + 4 * (16 * LDT + 16 * LDP));
+  return sizeof(float) * (size_t)((NT <= 4 ? 1 : 2) * Spad * 65 + Spad + 4 * 16 * LDP);
 }
 inline size_t bwd_lds_bytes(int NT) {
   const int Spad = NT * 16, LDP = Spad + 2;

@@ -33,7 +33,8 @@ namespace {
 int g_force_bn = 0;       // tuning knobs (vl_debug_set): 0 = automatic
 int g_force_generic = 0;
 int g_wave_rows = 4;      // 2: 512-thread workgroups (8 waves), 4: 1024-thread workgroups (16 waves)
-int g_alias_rows = 0;     // timing experiment only: A rows wrap modulo this (makes the A operand cache resident)
+int g_alias_rows = 0;
+int g_ablate = 0;     // timing experiment only: A rows wrap modulo this (makes the A operand cache resident)
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -46,6 +47,7 @@ struct GemmArgs {
   bf16_raw* out_hi; bf16_raw* out_lo; bf16_raw* aux16; long ld16;
   int tiles_m, tiles_n;
   int alias_rows;               // debug / timing experiment (0 = off)
+  int ablate;                   // timing experiment only (wrong results): 1 = no DMA inside the K loop
   int vec8;                     // 1: additionally 16-byte bf16 epilogue accesses are legal (ld16 % 8 == 0, 16-B pointers)
   int vec;                      // 1: leading dimensions / pointers allow the 16-byte (fp32) / 8-byte (bf16) epilogue
   int splits;                   // TN kernel: number of K-ranges (1-D grid over splits x tiles)
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
   __syncthreads();  // waits vmcnt(0) for the DMA, then the workgroup barrier
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
     if (NSPLIT == 1) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -612,6 +614,7 @@ int launch2w(GemmArgs a, hipStream_t stream, int splits) {
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + BN - 1) / BN;
   a.alias_rows = g_alias_rows;
+  a.ablate = g_ablate;
   hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, BN, WM>), dim3(a.tiles_m * a.tiles_n, splits), dim3(WM * 256), lds,
                      stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt(fast)");
@@ -775,6 +778,7 @@ extern "C" int vl_debug_set(int key, int value) {
   else if (key == 2) g_force_generic = value;
   else if (key == 3) g_alias_rows = value;
   else if (key == 4) g_wave_rows = value;
+  else if (key == 6) g_ablate = value;
   else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
   return 0;
 }

@@ -30,8 +30,9 @@ def main():
     L = _lib.lib()
     shapes = [("qkv   fwd", 14336, 2304, 768), ("oproj fwd", 14336, 768, 768), ("ffn1  fwd", 14336, 3072, 768),
               ("ffn2  fwd", 14336, 768, 3072), ("small-A  ", 2048, 768, 3072)]
-    variants = [("generic", dict(g=1, bn=0)), ("bn256-w8", dict(g=0, bn=256, wr=2)), ("bn192-w8", dict(g=0, bn=192, wr=2)),
-                ("bn256-w16", dict(g=0, bn=256, wr=4)), ("bn192-w16", dict(g=0, bn=192, wr=4))]
+    variants = [("bn256-w16", dict(g=0, bn=256, wr=4)), ("bn192-w16", dict(g=0, bn=192, wr=4)),
+                ("bn256-w16-noDMA", dict(g=0, bn=256, wr=4, ab=1)), ("bn192-w16-noDMA", dict(g=0, bn=192, wr=4, ab=1)),
+                ("bn256-w8-noDMA", dict(g=0, bn=256, wr=2, ab=1))]
     for passes in (1, 3):
         print("== passes %d ==" % passes)
         for name, M, N, K in shapes:
@@ -51,6 +52,7 @@ def main():
                 L.vl_debug_set(1, v["bn"])
                 L.vl_debug_set(3, v.get("alias", 0))
                 L.vl_debug_set(4, v.get("wr", 2))
+                L.vl_debug_set(6, v.get("ab", 0))
                 def run():
                     it[0] += 1
                     ops.gemm_nt(a_list[it[0] % nbuf], al_list[it[0] % len(al_list)], b, bl, M, N, K, passes, EPI_F32,
@@ -62,6 +64,7 @@ def main():
     L.vl_debug_set(2, 0)
     L.vl_debug_set(3, 0)
     L.vl_debug_set(4, 4)
+    L.vl_debug_set(6, 0)
 
 
 if __name__ == "__main__":
