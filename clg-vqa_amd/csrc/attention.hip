@@ -228,30 +228,43 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 
   const int nqt = (S + 15) >> 4;
   const int i16 = lane & 15, k4 = lane >> 4;
+  // software pipeline over the query tiles: the global loads of tile qt+1 (Q, dO, O, LSE: one float4 / ushort4 per
+  // thread) are issued before tile qt's MFMAs and consumed at the top of the next trip, so their HBM latency is off
+  // the critical path instead of being paid once per tile
+  const int prow = tid >> 4, pc4 = tid & 15;
+  float4 nq = make_float4(0.f, 0.f, 0.f, 0.f), nd = nq;
+  ushort4 noh = make_ushort4(0, 0, 0, 0), nol = noh;
+  float nlse = INFINITY;
+  auto prefetch = [&](int qt) {
+    const int q = qt * 16 + prow;
+    nq = nd = make_float4(0.f, 0.f, 0.f, 0.f);
+    noh = nol = make_ushort4(0, 0, 0, 0);
+    nlse = INFINITY;  // +inf -> P = 0 for padded queries
+    if (qt < nqt && q < S) {
+      nq = *reinterpret_cast<const float4*>(base + (long)q * ld + pc4 * 4);
+      const long off = ((long)b * S + q) * p.H + h * DH + pc4 * 4;
+      nd = *reinterpret_cast<const float4*>(p.dctx + off);
+      noh = *reinterpret_cast<const ushort4*>(p.ctx_hi + off);
+      nol = *reinterpret_cast<const ushort4*>(p.ctx_lo + off);
+      if (pc4 == 0) nlse = p.lse[((long)b * p.nh + h) * S + q];
+    }
+  };
+  prefetch(0);
   for (int qt = 0; qt < nqt; ++qt) {
-    {  // 256 threads stage the 16 x 64 Q and dO tiles (one float4 each) and delta = rowsum(dO * O)
-      const int row = tid >> 4, c4 = tid & 15, q = qt * 16 + row;
-      float4 vq = make_float4(0.f, 0.f, 0.f, 0.f), vd = vq;
-      float part = 0.f;
-      if (q < S) {
-        vq = *reinterpret_cast<const float4*>(base + (long)q * ld + c4 * 4);
-        const long off = ((long)b * S + q) * p.H + h * DH + c4 * 4;
-        vd = *reinterpret_cast<const float4*>(p.dctx + off);
-        const ushort4 oh = *reinterpret_cast<const ushort4*>(p.ctx_hi + off);
-        const ushort4 ol = *reinterpret_cast<const ushort4*>(p.ctx_lo + off);
-        part = vd.x * (bf16_to_f32(oh.x) + bf16_to_f32(ol.x)) + vd.y * (bf16_to_f32(oh.y) + bf16_to_f32(ol.y)) +
-               vd.z * (bf16_to_f32(oh.z) + bf16_to_f32(ol.z)) + vd.w * (bf16_to_f32(oh.w) + bf16_to_f32(ol.w));
-      }
+    {  // the 16 x 64 Q and dO tiles (one float4 per thread) -> LDS, and delta = rowsum(dO * O)
+      float part = nd.x * (bf16_to_f32(noh.x) + bf16_to_f32(nol.x)) + nd.y * (bf16_to_f32(noh.y) + bf16_to_f32(nol.y)) +
+                   nd.z * (bf16_to_f32(noh.z) + bf16_to_f32(nol.z)) + nd.w * (bf16_to_f32(noh.w) + bf16_to_f32(nol.w));
       part = group16_sum(part);  // the 16 threads of a row are 16 consecutive lanes of one wave
-      float2* dq_ = reinterpret_cast<float2*>(sQ + row * LDT + c4 * 4);
-      dq_[0] = make_float2(vq.x, vq.y); dq_[1] = make_float2(vq.z, vq.w);
-      float2* dd_ = reinterpret_cast<float2*>(sdO + row * LDT + c4 * 4);
-      dd_[0] = make_float2(vd.x, vd.y); dd_[1] = make_float2(vd.z, vd.w);
-      if (c4 == 0) {
-        sdelta[row] = part;
-        slse[row] = q < S ? p.lse[((long)b * p.nh + h) * S + q] : INFINITY;  // +inf -> P = 0 for padded queries
+      float2* dq_ = reinterpret_cast<float2*>(sQ + prow * LDT + pc4 * 4);
+      dq_[0] = make_float2(nq.x, nq.y); dq_[1] = make_float2(nq.z, nq.w);
+      float2* dd_ = reinterpret_cast<float2*>(sdO + prow * LDT + pc4 * 4);
+      dd_[0] = make_float2(nd.x, nd.y); dd_[1] = make_float2(nd.z, nd.w);
+      if (pc4 == 0) {
+        sdelta[prow] = part;
+        slse[prow] = nlse;
       }
     }
+    prefetch(qt + 1);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < MAXKT; ++i) {
