@@ -141,6 +141,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="samples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sft", action="store_true", help="configs[2]: train under a Bernoulli(0.59) SFT mask")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs[1..4]: c2 UC2 dense (the headline), c3 = c2 + SFT masks, c4 M3P with 100 "
+                         "boxes, c5 UC2 with 100 boxes + SFT at bs 128")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank logic on a single GPU)")
     args = ap.parse_args()
@@ -169,9 +172,24 @@ def main():
     timer = GemmTimer()
     timer.wrap(ops)
 
-    config = BertConfig.from_dict(uc2_full_cfg())
+    num_boxes, num_locs, l2n = 36, 7, False
+    if args.workload in ("c3", "c5"):
+        args.sft = True
+    if args.workload == "c5":
+        num_boxes, args.batch = 100, (128 if args.batch == 256 else args.batch)
     torch.manual_seed(1234)  # identical replicas on every rank (apex DDP broadcasts from rank 0 instead)
-    model = BertForVLTasks(config, TASK_CFG, ["TASK15"]).to(dev)
+    if args.workload == "c4":
+        from clg_vqa_amd.config import M3PConfig
+        from clg_vqa_amd.m3p import M3PForVLTasks
+        num_boxes, num_locs, l2n = 100, 5, True
+        config = M3PConfig.from_dict(dict(n_heads=12, emb_dim=768, n_layers=12, n_words=250002, vocab_size=250002,
+                                          hidden_size=768, pooler_size=768, clf_hidden_size=1536, num_locs=5,
+                                          image_embeddings="m3p", model="roberta", fusion_method="text",
+                                          norm_embeddings=True))  # volta/config/m3p_base.json
+        model = M3PForVLTasks(config, TASK_CFG, ["TASK15"]).to(dev)
+    else:
+        config = BertConfig.from_dict(uc2_full_cfg())
+        model = BertForVLTasks(config, TASK_CFG, ["TASK15"]).to(dev)
     if args.sft:
         from torch.nn.utils import prune
         sys.path.insert(0, ROOT)
@@ -187,7 +205,8 @@ def main():
     # reference hyper-parameters: experiments/zero_shot/uc2/xgqa/train.dtu.sh:20-28
     opt = FusedAdamW(model, base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True,
                      max_grad_norm=1.0, warmup_steps=100, t_total=100000)
-    batch = tuple(t.to(dev) for t in make_batch(args.batch, seed=1234 + rank))
+    batch = tuple(t.to(dev) for t in make_batch(args.batch, num_boxes=num_boxes, num_locs=num_locs, l2_normalize=l2n,
+                                                seed=1234 + rank))
     crit = torch.nn.CrossEntropyLoss()
 
     def step():
@@ -233,7 +252,9 @@ def main():
                                              frac=round(a1 / MFMA_BF16_PEAK_TFLOPS, 4), launches=gs[1]["launches"],
                                              avg_launch_us=round(1e3 * gs[1]["ms"] / gs[1]["launches"], 2))
         line = {
-            "metric": "VQA train samples/sec (UC2, 36 boxes, seq56, bs256)",
+            "metric": "VQA train samples/sec (UC2, 36 boxes, seq56, bs256)" if args.workload in ("c2", "c3") else
+                      "VQA train samples/sec (%s, %d boxes, seq%d, bs%d) [not the headline config]" % (
+                          "M3P" if args.workload == "c4" else "UC2", num_boxes, 20 + num_boxes, args.batch),
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -241,7 +262,7 @@ def main():
                                    "T=20 + V=36 (S=56), bs %d per GPU, %s fine-tune with_prior, dropout 0.1, "
                                    "full step = fwd+loss+bwd+allreduce+clip+AdamW+zero_grad" % (
                                        args.batch, "SFT-masked" if args.sft else "dense"),
-                       "global_batch": world * args.batch, "seq_len": 56, "parallelism": "dp%d" % world,
+                       "baseline_config": args.workload, "global_batch": world * args.batch, "seq_len": 20 + num_boxes, "parallelism": "dp%d" % world,
                        "precision": "forward GEMMs 3-pass split bf16 MFMA (fp32-grade, logits within 1e-3); attention "
                                     "core fp32 MFMA; backward GEMMs bf16 MFMA; fp32 residual stream / LN / optimizer",
                        "algorithmic_tflop_per_step": round(29.241e-3 * world * args.batch, 3), "final_loss": final_loss},
