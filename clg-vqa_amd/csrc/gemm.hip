@@ -34,6 +34,7 @@ int g_force_bn = 0;       // tuning knobs (vl_debug_set): 0 = automatic
 int g_force_generic = 0;
 int g_wave_rows = 4;      // 2: 512-thread workgroups (8 waves), 4: 1024-thread workgroups (16 waves)
 int g_alias_rows = 0;
+int g_pingpong = 1;   // 1-pass products on the 8-wave ping-pong kernel (key 7)
 int g_ablate = 0;     // timing experiment only: A rows wrap modulo this (makes the A operand cache resident)
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -346,6 +347,169 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 1-pass "ping-pong" path (backward dX products): 256 x 256 tile, BK = 64, 8 waves (2 x 4), each wave owns
+// 128 x 64 of the tile as four 64 x 32 quadrants {rows qm*128 + wr*64.., cols qn*128 + wc*32..}.  One workgroup per
+// CU (128 KiB LDS: 2 K-tiles x {A0, A1, B0, B1} half-tiles of 128 rows x 128 B), two waves per SIMD (wave w and
+// w + 4 = the two wave rows).  A K-tile is consumed in 4 phases, one quadrant each:
+//      [ds_read the sub-tiles the quadrant needs | LDS-DMA one half-tile of a later K-tile | s_waitcnt vmcnt(8)]
+//      s_barrier   [lgkmcnt(0); 16 MFMA at raised priority]   s_barrier
+// and the second wave row runs one barrier behind the first, so on every SIMD one wave is in its MFMA section while
+// the other issues its LDS reads / DMA: the matrix pipe never waits for a load section.  Hazards, by barrier count:
+//  * RAW: a half-tile issued in phase q is retired by every wave's vmcnt(8) in phase q+4 (8 = the 4 younger
+//    half-tiles x 2 DMA instructions per wave) and first read in phase >= q+5, i.e. after a barrier that follows
+//    every wave's wait even with the one-barrier stagger.
+//  * WAR: a half-tile is re-staged >= 2 phases after the phase of its last ds_read (A0, B0: read in phase 0 --
+//    B0 stays in registers for phase 3 -- re-staged in phases 2, 3; B1: phase 1 -> next phase 0; A1: phase 2 ->
+//    next phase 1).
+// Quadrant order (0,0) (0,1) (1,1) (1,0): consecutive phases share the A or the B sub-tile, so the load sections
+// carry 12 / 4 / 8 / 0 ds_read_b128.
+// ---------------------------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
+  constexpr int HALF = 16384, STAGE = 65536;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = swz / p.tiles_n, tn = swz - tm * p.tiles_n;
+  const int row0 = tm * 256, col0 = tn * 256;
+  const int nk = p.K >> 6;
+
+  // DMA sources: half-tile x in {A0, A1, B0, B1}; this wave stages units 2*wave, 2*wave+1 (8 rows x 128 B each);
+  // lane -> (row, physical 16-B chunk); the chunk XOR (row>>1)&7 is applied on the source and undone by the reads
+  const bf16_raw* src[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 8 * (2 * wave + j) + (lane >> 3);
+      const int lc = (lane & 7) ^ ((r >> 1) & 7);
+      const bool isB = x >= 2;
+      int g = (isB ? col0 : row0) + (x & 1) * 128 + r;
+      const int lim = (isB ? p.N : p.M) - 1;
+      g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
+      src[x][j] = (isB ? p.b_hi : p.a_hi) + (long)g * (isB ? p.ldb : p.lda) + lc * 8;
+    }
+#define G3_ISSUE(x, kt)                                                                                          \
+  do {                                                                                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                             \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][j_] + (long)(kt) * 64),                              \
+                                         (lds_ptr_t)(smem + ((kt) & 1) * STAGE + (x) * HALF + (2 * wave + j_) * 1024), \
+                                         16, 0, 0);                                                              \
+  } while (0)
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  const int sw = (frow >> 1) & 7;
+  const int a_lane = (wr * 64 + frow) * 128, b_lane = (wc * 32 + frow) * 128;
+  const int c0 = ((fk ^ sw) << 4), c1 = (((4 + fk) ^ sw) << 4);
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define G3_READ_A(st, qm)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+    fa[i][0] = *reinterpret_cast<const bf16x8*>((st) + (qm) * HALF + a_lane + i * 2048 + c0);                    \
+    fa[i][1] = *reinterpret_cast<const bf16x8*>((st) + (qm) * HALF + a_lane + i * 2048 + c1);                    \
+  }
+#define G3_READ_B(st, qn, fb)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
+    fb[j][0] = *reinterpret_cast<const bf16x8*>((st) + (2 + (qn)) * HALF + b_lane + j * 2048 + c0);              \
+    fb[j][1] = *reinterpret_cast<const bf16x8*>((st) + (2 + (qn)) * HALF + b_lane + j * 2048 + c1);              \
+  }
+#define G3_WAIT(issued)                                                                                          \
+  do {                                                                                                           \
+    if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                 \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+  } while (0)
+#define G3_MFMA(qm, qn, fb)                                                                                      \
+  do {                                                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+        acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[qm][qn][i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+  } while (0)
+
+  // prologue: K-tile 0 complete, A0 / B0 of K-tile 1 in flight
+  G3_ISSUE(0, 0); G3_ISSUE(2, 0); G3_ISSUE(3, 0); G3_ISSUE(1, 0);
+  if (nk > 1) {
+    G3_ISSUE(0, 1); G3_ISSUE(2, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second wave row runs one barrier behind
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    // phase 0: quadrant (0,0)
+    G3_READ_B(st, 0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    G3_READ_A(st, 0);
+    if (n1) G3_ISSUE(3, kt + 1);
+    G3_WAIT(n1);
+    G3_MFMA(0, 0, fb0);
+    // phase 1: quadrant (0,1)
+    G3_READ_B(st, 1, fb1);
+    if (n1) G3_ISSUE(1, kt + 1);
+    G3_WAIT(n1);
+    G3_MFMA(0, 1, fb1);
+    // phase 2: quadrant (1,1)
+    G3_READ_A(st, 1);
+    if (n2) G3_ISSUE(0, kt + 2);
+    G3_WAIT(n2);
+    G3_MFMA(1, 1, fb1);
+    // phase 3: quadrant (1,0)
+    if (n2) G3_ISSUE(2, kt + 2);
+    G3_WAIT(n2);
+    G3_MFMA(1, 0, fb0);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();  // matches the stagger barrier
+#undef G3_ISSUE
+#undef G3_READ_A
+#undef G3_READ_B
+#undef G3_WAIT
+#undef G3_MFMA
+
+  float* out32 = p.out32;
+#pragma unroll
+  for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = row0 + qm * 128 + wr * 64 + i * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n0 = col0 + qn * 128 + wc * 32 + j * 16 + 4 * (lane >> 4);
+          if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // TN fast path for the weight gradients: C[M,N] = A^T B with A [K][M], B [K][N] both "k-strided" (row = one of the
 // B*S batch rows), i.e. dW = dY^T X straight from the row-major activations -- no transposed copies.  Same 256 x BN
 // tile / 8 waves / LDS-DMA double buffer as gemm2_kernel; the LDS image is [k][cols] and MFMA fragments (8 k-values
@@ -620,6 +784,22 @@ int launch2w(GemmArgs a, hipStream_t stream, int splits) {
   VL_CHECK_LAUNCH("vl_gemm_nt(fast)");
   return 0;
 }
+template <int EPI>
+int launch3(GemmArgs a, hipStream_t stream) {
+  const size_t lds = 131072;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_n = (a.N + 255) / 256;
+  hipLaunchKernelGGL((gemm3_kernel<EPI>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+  VL_CHECK_LAUNCH("vl_gemm_nt(ping-pong)");
+  return 0;
+}
 template <int NSPLIT, int EPI, int BN>
 int launch2(const GemmArgs& a, hipStream_t stream, int splits) {
   return g_wave_rows == 4 ? launch2w<NSPLIT, EPI, BN, 4>(a, stream, splits) : launch2w<NSPLIT, EPI, BN, 2>(a, stream, splits);
@@ -649,6 +829,9 @@ inline bool fast_ok(int64_t M, int64_t K, int64_t k_len, int passes) {
 
 template <int NSPLIT, int EPI>
 int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
+  if (NSPLIT == 1 && splits == 1 && g_pingpong && !g_force_generic && a.M >= 256 && a.N >= 256 && (a.K % 64) == 0 &&
+      (EPI == VL_EPI_F32 || EPI == VL_EPI_DGELU_BF16 || EPI == VL_EPI_BF16))
+    return launch3<EPI>(a, s);
   if (fast_ok(a.M, a.K, a.k_len, NSPLIT)) {
     switch (pick_bn(a.M, a.N, splits)) {
       case 256: return launch2<NSPLIT, EPI, 256>(a, s, splits);
@@ -779,6 +962,7 @@ extern "C" int vl_debug_set(int key, int value) {
   else if (key == 3) g_alias_rows = value;
   else if (key == 4) g_wave_rows = value;
   else if (key == 6) g_ablate = value;
+  else if (key == 7) g_pingpong = value;
   else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
   return 0;
 }

@@ -52,6 +52,33 @@ def test_gemm_single_pass_bf16(M, N, K):
     torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(K / 256))
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (300, 260, 192), (1000, 700, 448), (2048, 768, 3072),
+                                   (3584, 3072, 768), (513, 257, 2304)])
+def test_gemm_pingpong_kernel(M, N, K):
+    """The 8-wave ping-pong kernel behind the 1-pass products (counted vmcnt + staggered barriers): edges, every K-tile
+    count parity, and a repeat screen -- the kernel is deterministic, so any run-to-run difference is a staging race."""
+    from clg_vqa_amd import _lib
+    a = _rand(M, K, seed=20).to(BF16)
+    b = _rand(N, K, seed=21).to(BF16)
+    ref = (a.double() @ b.double().t()).float()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_nt(a, None, b, None, M, N, K, 1, EPI_F32, out32=out)
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(max(K, 256) / 256))
+    _lib.lib().vl_debug_set(7, 0)  # the older single-barrier kernel computes the same sums in the same k order
+    try:
+        old = torch.empty_like(out)
+        ops.gemm_nt(a, None, b, None, M, N, K, 1, EPI_F32, out32=old)
+    finally:
+        _lib.lib().vl_debug_set(7, 1)
+    assert torch.equal(out, old)
+    filler = torch.empty(64 << 20, device=DEV)
+    for it in range(12):
+        again = torch.full((M, N), float("nan"), device=DEV)
+        filler.normal_()  # evict L2 / perturb timing between runs
+        ops.gemm_nt(a, None, b, None, M, N, K, 1, EPI_F32, out32=again)
+        assert torch.equal(again, out), it
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 200, 264), (1024, 2304, 768), (256, 1842, 768),
                                    (512, 768, 3072), (700, 768, 2048), (300, 200, 96), (999, 333, 32)])
 def test_gemm_three_pass_is_fp32_grade(M, N, K):

@@ -29,10 +29,9 @@ def bench(fn, iters=20):
 def main():
     L = _lib.lib()
     shapes = [("qkv   fwd", 14336, 2304, 768), ("oproj fwd", 14336, 768, 768), ("ffn1  fwd", 14336, 3072, 768),
-              ("ffn2  fwd", 14336, 768, 3072), ("small-A  ", 2048, 768, 3072)]
-    variants = [("bn256-w16", dict(g=0, bn=256, wr=4)), ("bn192-w16", dict(g=0, bn=192, wr=4)),
-                ("bn256-w16-noDMA", dict(g=0, bn=256, wr=4, ab=1)), ("bn192-w16-noDMA", dict(g=0, bn=192, wr=4, ab=1)),
-                ("bn256-w8-noDMA", dict(g=0, bn=256, wr=2, ab=1))]
+              ("ffn2  fwd", 14336, 768, 3072), ("qkv   dX ", 14336, 768, 2304)]
+    variants = [("bn256-w16", dict(g=0, bn=256, wr=4, pp=0)), ("bn192-w16", dict(g=0, bn=192, wr=4, pp=0)),
+                ("pingpong", dict(g=0, bn=0, wr=4, pp=1))]
     for passes in (1, 3):
         print("== passes %d ==" % passes)
         for name, M, N, K in shapes:
@@ -53,18 +52,27 @@ def main():
                 L.vl_debug_set(3, v.get("alias", 0))
                 L.vl_debug_set(4, v.get("wr", 2))
                 L.vl_debug_set(6, v.get("ab", 0))
+                L.vl_debug_set(7, v.get("pp", 0))
                 def run():
                     it[0] += 1
                     ops.gemm_nt(a_list[it[0] % nbuf], al_list[it[0] % len(al_list)], b, bl, M, N, K, passes, EPI_F32,
                                 out32=out)
                 us = bench(run)
                 row.append("%s %7.1f us %6.0f TF" % (vname, us, 2.0 * M * N * K / us / 1e6))
+            if passes == 1:  # library (hipBLASLt via torch) on the same cold operands, bf16 out: the speed to beat
+                outb = torch.empty(M, N, device=DEV, dtype=BF16)
+                def run_lib():
+                    it[0] += 1
+                    torch.matmul(a_list[it[0] % nbuf], b.t(), out=outb)
+                us = bench(run_lib)
+                row.append("torch.matmul %7.1f us %6.0f TF" % (us, 2.0 * M * N * K / us / 1e6))
             print("%s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
     L.vl_debug_set(1, 0)
     L.vl_debug_set(2, 0)
     L.vl_debug_set(3, 0)
     L.vl_debug_set(4, 4)
     L.vl_debug_set(6, 0)
+    L.vl_debug_set(7, 1)
 
 
 if __name__ == "__main__":
