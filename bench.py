@@ -163,7 +163,7 @@ def main():
     torch.cuda.set_device(dev)
 
     from helpers import TASK_CFG
-    from clg_vqa_amd import ops, task_utils
+    from clg_vqa_amd import _lib, ops, task_utils
     from clg_vqa_amd.config import BertConfig
     from clg_vqa_amd.encoders import BertForVLTasks
     from clg_vqa_amd.optim import FusedAdamW
@@ -172,6 +172,9 @@ def main():
     timer = GemmTimer()
     timer.wrap(ops)
 
+    for kv in filter(None, os.environ.get("VL_DEBUG", "").split(",")):  # tuning knobs, e.g. VL_DEBUG=7:0,8:1
+        k, v = kv.split(":")
+        _lib.lib().vl_debug_set(int(k), int(v))
     num_boxes, num_locs, l2n = 36, 7, False
     if args.workload in ("c3", "c5"):
         args.sft = True

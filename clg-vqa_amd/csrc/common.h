@@ -35,7 +35,7 @@ __device__ __forceinline__ void split_bf16(float x, bf16_raw& hi, bf16_raw& lo) 
 // instead of libm's ~40-instruction erff.  exp(-x^2/2) is shared between the cdf and the pdf in the gradient.
 __device__ __forceinline__ void vl_cdf_pdf(float x, float& cdf, float& e) {
   const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));  // v_rcp_f32 (1 ulp), not the IEEE division sequence
   e = __expf(-0.5f * x * x);  // = exp(-(x/sqrt2)^2)
   float poly = fmaf(1.061405429f, t, -1.453152027f);
   poly = fmaf(poly, t, 1.421413741f);

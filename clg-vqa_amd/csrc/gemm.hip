@@ -34,7 +34,8 @@ int g_force_bn = 0;       // tuning knobs (vl_debug_set): 0 = automatic
 int g_force_generic = 0;
 int g_wave_rows = 4;      // 2: 512-thread workgroups (8 waves), 4: 1024-thread workgroups (16 waves)
 int g_alias_rows = 0;
-int g_pingpong = 1;   // 1-pass products on the 8-wave ping-pong kernel (key 7)
+int g_pingpong = 1;   // 8-wave ping-pong kernel (key 7): 0 = off, 1 = automatic tile width, 2 / 3 = force 256 / 192, 4 = cost model only
+int g_pp3 = 1;        // key 8: 3-pass products on the ping-pong kernel too
 int g_ablate = 0;     // timing experiment only: A rows wrap modulo this (makes the A operand cache resident)
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -347,103 +348,172 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// 1-pass "ping-pong" path (backward dX products): 256 x 256 tile, BK = 64, 8 waves (2 x 4), each wave owns
-// 128 x 64 of the tile as four 64 x 32 quadrants {rows qm*128 + wr*64.., cols qn*128 + wc*32..}.  One workgroup per
-// CU (128 KiB LDS: 2 K-tiles x {A0, A1, B0, B1} half-tiles of 128 rows x 128 B), two waves per SIMD (wave w and
-// w + 4 = the two wave rows).  A K-tile is consumed in 4 phases, one quadrant each:
-//      [ds_read the sub-tiles the quadrant needs | LDS-DMA one half-tile of a later K-tile | s_waitcnt vmcnt(8)]
-//      s_barrier   [lgkmcnt(0); 16 MFMA at raised priority]   s_barrier
-// and the second wave row runs one barrier behind the first, so on every SIMD one wave is in its MFMA section while
-// the other issues its LDS reads / DMA: the matrix pipe never waits for a load section.  Hazards, by barrier count:
-//  * RAW: a half-tile issued in phase q is retired by every wave's vmcnt(8) in phase q+4 (8 = the 4 younger
-//    half-tiles x 2 DMA instructions per wave) and first read in phase >= q+5, i.e. after a barrier that follows
-//    every wave's wait even with the one-barrier stagger.
+// "ping-pong" path (all large products with K % 64 == 0 / K % 32 == 0): 8 waves, one workgroup per CU, two waves per
+// SIMD (wave w and w + 4).  Two tile configurations
+//      CFG 0: 256 x 256, waves 2 (M) x 4 (N), wave tile 128 x 64 = four 64 x 32 quadrants
+//      CFG 1: 256 x 192, waves 4 (M) x 2 (N), wave tile  64 x 96 = four 32 x 48 quadrants   (N = 768 -> 224 tiles)
+// quadrant (qm, qn) of wave (wr, wc) = rows qm*128 + wr*MI*16 .., cols qn*BH + wc*NJ*16 ..: it needs exactly one
+// A half-tile (128 rows x 128 B) and one B half-tile (BH rows x 128 B) of the K-tile.  A 128-B LDS row holds 64 k
+// values (1 pass) or 32 k values as [hi | lo] (3 passes), so both precisions share the staging and the reads.
+// LDS: 2 K-tiles x {A0, A1, B0, B1}.  A K-tile is consumed in 4 phases, one quadrant each:
+//      [ds_read the sub-tiles the quadrant needs | LDS-DMA one half-tile of a later K-tile | s_waitcnt vmcnt(N)]
+//      s_barrier   [lgkmcnt(0); the quadrant's MFMAs at raised priority]   s_barrier
+// and waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA section while the other
+// issues its LDS reads / DMA: the matrix pipe never waits for a load section.  Hazards, by barrier count:
+//  * RAW: a half-tile issued in phase q is retired by every wave's counted vmcnt in phase q+4 (N = the DMA
+//    instructions of the 4 younger half-tiles) and first read in phase >= q+5, i.e. after a barrier that follows every
+//    wave's wait even with the one-barrier stagger.
 //  * WAR: a half-tile is re-staged >= 2 phases after the phase of its last ds_read (A0, B0: read in phase 0 --
 //    B0 stays in registers for phase 3 -- re-staged in phases 2, 3; B1: phase 1 -> next phase 0; A1: phase 2 ->
 //    next phase 1).
-// Quadrant order (0,0) (0,1) (1,1) (1,0): consecutive phases share the A or the B sub-tile, so the load sections
-// carry 12 / 4 / 8 / 0 ds_read_b128.
+// Quadrant order (0,0) (0,1) (1,1) (1,0): consecutive phases share the A or the B sub-tile.
+// Bank swizzle f(row) (XOR on the 16-B chunk index, applied on the DMA source address and undone by the reads) is
+// conflict-free both for 16 consecutive rows and for the permuted rows {0-3, 8-11, 16-19, 24-27} + 4*(j&1) that the
+// paired n-tiles of the 16-bit epilogues read (see gemm2_kernel).
 // ---------------------------------------------------------------------------------------------------------------
-template <int EPI>
+__device__ __forceinline__ int swz3(int row) {
+  return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 4) ^ (row >> 2)) & 1) << 2);
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8, "unsupported count");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+template <int NSPLIT, int EPI, int CFG>
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
-  constexpr int HALF = 16384, STAGE = 65536;
+  constexpr int WR = CFG == 0 ? 2 : 4, WC = 8 / WR;        // wave grid
+  constexpr int MI = CFG == 0 ? 4 : 2, NJ = CFG == 0 ? 2 : 3;  // 16 x 16 MFMA tiles per quadrant
+  constexpr int AH = WR * MI * 16, BH = WC * NJ * 16;      // rows per half-tile: 128, 128 | 96
+  constexpr int BNT = 2 * BH;                               // tile width
+  constexpr int UB = BH / 8;                                // 1-KiB DMA units per B half-tile (16 | 12)
+  constexpr bool BSHORT = UB < 16;                          // waves 4-7 stage one unit of a B half-tile, not two
+  constexpr int OFF_A1 = AH * 128, OFF_B0 = 2 * AH * 128, OFF_B1 = OFF_B0 + BH * 128, STAGE = OFF_B1 + BH * 128;
+  constexpr int KSTEP = NSPLIT == 3 ? 32 : 64;
+  constexpr bool PAIR = (EPI != VL_EPI_F32);
+  constexpr int NJP = PAIR ? (NJ & ~1) : 0;                 // n-tiles [0, NJP) of a quadrant are paired
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / WC, wc = wave % WC;
+  const bool late = wave >= 4;  // the wave group that runs one barrier behind
 
   const int nwg = p.tiles_m * p.tiles_n;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tm = swz / p.tiles_n, tn = swz - tm * p.tiles_n;
-  const int row0 = tm * 256, col0 = tn * 256;
-  const int nk = p.K >> 6;
+  const int row0 = tm * 256, col0 = tn * BNT;
+  const int nk = p.K / KSTEP;
 
-  // DMA sources: half-tile x in {A0, A1, B0, B1}; this wave stages units 2*wave, 2*wave+1 (8 rows x 128 B each);
-  // lane -> (row, physical 16-B chunk); the chunk XOR (row>>1)&7 is applied on the source and undone by the reads
+  // DMA sources: half-tile x in {A0, A1, B0, B1}; unit u = wave + 8*j (8 rows x 128 B); lane -> (row, physical chunk)
   const bf16_raw* src[4][2];
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int r = 8 * (2 * wave + j) + (lane >> 3);
-      const int lc = (lane & 7) ^ ((r >> 1) & 7);
       const bool isB = x >= 2;
-      int g = (isB ? col0 : row0) + (x & 1) * 128 + r;
+      const int r = 8 * (wave + 8 * j) + (lane >> 3);
+      const int lc = (lane & 7) ^ swz3(r);  // logical chunk that lands at physical position lane & 7
+      int g = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + r;
       const int lim = (isB ? p.N : p.M) - 1;
       g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
-      src[x][j] = (isB ? p.b_hi : p.a_hi) + (long)g * (isB ? p.ldb : p.lda) + lc * 8;
+      const bf16_raw* base;
+      int koff;
+      if (NSPLIT == 3) {
+        base = isB ? ((lc & 4) ? p.b_lo : p.b_hi) : ((lc & 4) ? p.a_lo : p.a_hi);
+        koff = (lc & 3) * 8;
+      } else {
+        base = isB ? p.b_hi : p.a_hi;
+        koff = lc * 8;
+      }
+      src[x][j] = base + (long)g * (isB ? p.ldb : p.lda) + koff;
     }
+  constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
 #define G3_ISSUE(x, kt)                                                                                          \
   do {                                                                                                           \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                                                             \
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][j_] + (long)(kt) * 64),                              \
-                                         (lds_ptr_t)(smem + ((kt) & 1) * STAGE + (x) * HALF + (2 * wave + j_) * 1024), \
-                                         16, 0, 0);                                                              \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][0] + (long)(kt) * KSTEP),                                \
+                                     (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + wave * 1024), 16, 0, 0);  \
+    if (!(BSHORT && (x) >= 2 && late))                                                                           \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][1] + (long)(kt) * KSTEP),                              \
+                                       (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + (wave + 8) * 1024), 16, 0, 0); \
+  } while (0)
+  // wait until everything older than the youngest (nA A-half-tiles + nB B-half-tiles) has landed
+#define G3_WAIT_YOUNGER(nA, nB)                                                                                  \
+  do {                                                                                                           \
+    if (BSHORT && late) wait_vmcnt<2 * (nA) + (nB)>();                                                          \
+    else wait_vmcnt<2 * (nA) + 2 * (nB)>();                                                                      \
+  } while (0)
+#define G3_WAIT(issued)                                                                                          \
+  do {                                                                                                           \
+    if (issued) G3_WAIT_YOUNGER(2, 2);                                                                           \
+    else wait_vmcnt<0>();                                                                                        \
   } while (0)
 
-  f32x4 acc[2][2][4][2];
+  f32x4 acc[2][2][MI][NJ];
 #pragma unroll
   for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
     for (int b_ = 0; b_ < 2; ++b_)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // fragment byte offsets inside a half-tile: [tile][first / second 64-B half of the row], swizzle folded in
   const int frow = lane & 15, fk = lane >> 4;
-  const int sw = (frow >> 1) & 7;
-  const int a_lane = (wr * 64 + frow) * 128, b_lane = (wc * 32 + frow) * 128;
-  const int c0 = ((fk ^ sw) << 4), c1 = (((4 + fk) ^ sw) << 4);
+  int a_o[MI][2], b_o[NJ][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wr * (MI * 16) + i * 16 + frow;
+    a_o[i][0] = row * 128 + ((fk ^ swz3(row)) << 4);
+    a_o[i][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wc * (NJ * 16) + (j < NJP ? 32 * (j >> 1) + 8 * (frow >> 2) + 4 * (j & 1) + (frow & 3) : j * 16 + frow);
+    b_o[j][0] = row * 128 + ((fk ^ swz3(row)) << 4);
+    b_o[j][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+  }
 
-  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+  bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
 #define G3_READ_A(st, qm)                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
-    fa[i][0] = *reinterpret_cast<const bf16x8*>((st) + (qm) * HALF + a_lane + i * 2048 + c0);                    \
-    fa[i][1] = *reinterpret_cast<const bf16x8*>((st) + (qm) * HALF + a_lane + i * 2048 + c1);                    \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
+    fa[i][0] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[i][0]);                               \
+    fa[i][1] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[i][1]);                               \
   }
 #define G3_READ_B(st, qn, fb)                                                                                    \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                               \
-    fb[j][0] = *reinterpret_cast<const bf16x8*>((st) + (2 + (qn)) * HALF + b_lane + j * 2048 + c0);              \
-    fb[j][1] = *reinterpret_cast<const bf16x8*>((st) + (2 + (qn)) * HALF + b_lane + j * 2048 + c1);              \
+  _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
+    fb[j][0] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                  \
+    fb[j][1] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                  \
   }
-#define G3_WAIT(issued)                                                                                          \
-  do {                                                                                                           \
-    if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                 \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
-  } while (0)
+  // 1 pass: [0] / [1] are the two 32-deep k halves of the row; 3 passes: [0] = hi, [1] = lo of one 32-deep k step and
+  // the products are issued product-major so that dependent accumulations are MI*NJ MFMAs apart
 #define G3_MFMA(qm, qn, fb)                                                                                      \
   do {                                                                                                           \
     __builtin_amdgcn_s_barrier();                                                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                                               \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
-        acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[qm][qn][i][j], 0, 0, 0); \
+    if (NSPLIT == 1) {                                                                                           \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                             \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
+          acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[qm][qn][i][j], 0, 0, 0); \
+    } else {                                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                             \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
+          acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][1], acc[qm][qn][i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                             \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
+          acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][1], fa[i][0], acc[qm][qn][i][j], 0, 0, 0); \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                             \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
+          acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][0], acc[qm][qn][i][j], 0, 0, 0); \
+    }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     __builtin_amdgcn_s_barrier();                                                                                \
@@ -453,12 +523,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   G3_ISSUE(0, 0); G3_ISSUE(2, 0); G3_ISSUE(3, 0); G3_ISSUE(1, 0);
   if (nk > 1) {
     G3_ISSUE(0, 1); G3_ISSUE(2, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    G3_WAIT_YOUNGER(1, 1);
   } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: the second wave row runs one barrier behind
+  if (late) __builtin_amdgcn_s_barrier();  // stagger
 
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
@@ -485,26 +555,35 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     G3_WAIT(n2);
     G3_MFMA(1, 0, fb0);
   }
-  if (wr == 0) __builtin_amdgcn_s_barrier();  // matches the stagger barrier
+  if (!late) __builtin_amdgcn_s_barrier();  // matches the stagger barrier
 #undef G3_ISSUE
+#undef G3_WAIT_YOUNGER
+#undef G3_WAIT
 #undef G3_READ_A
 #undef G3_READ_B
-#undef G3_WAIT
 #undef G3_MFMA
 
+  // epilogue.  D^T layout: lane&15 -> m inside the 16-row tile, 4*(lane>>4) + reg -> n inside the 16-col tile
   float* out32 = p.out32;
 #pragma unroll
   for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = row0 + qm * 128 + wr * 64 + i * 16 + (lane & 15);
+    for (int i = 0; i < MI; ++i) {
+      const int m = row0 + qm * AH + wr * (MI * 16) + i * 16 + (lane & 15);
       if (m >= p.M) continue;
 #pragma unroll
       for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n0 = col0 + qn * 128 + wc * 32 + j * 16 + 4 * (lane >> 4);
-          if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j]);
+        for (int j = 0; j < NJ; ++j) {
+          const int cb = col0 + qn * BH + wc * (NJ * 16);
+          if (j < NJP) {
+            if (j & 1) continue;
+            const int n0 = cb + 32 * (j >> 1) + 8 * (lane >> 4);
+            if (n0 < p.N) epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j]);
+          } else {
+            const int n0 = cb + j * 16 + 4 * (lane >> 4);
+            if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j]);
+          }
         }
     }
 }
@@ -784,25 +863,26 @@ int launch2w(GemmArgs a, hipStream_t stream, int splits) {
   VL_CHECK_LAUNCH("vl_gemm_nt(fast)");
   return 0;
 }
-template <int EPI>
+template <int NSPLIT, int EPI, int CFG>
 int launch3(GemmArgs a, hipStream_t stream) {
-  const size_t lds = 131072;
+  constexpr int BNT = CFG == 0 ? 256 : 192;
+  const size_t lds = 2 * (256 + BNT) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, CFG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
   a.tiles_m = (a.M + 255) / 256;
-  a.tiles_n = (a.N + 255) / 256;
-  hipLaunchKernelGGL((gemm3_kernel<EPI>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
+  a.tiles_n = (a.N + BNT - 1) / BNT;
+  hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt(ping-pong)");
   return 0;
 }
 template <int NSPLIT, int EPI, int BN>
 int launch2(const GemmArgs& a, hipStream_t stream, int splits) {
-  return g_wave_rows == 4 ? launch2w<NSPLIT, EPI, BN, 4>(a, stream, splits) : launch2w<NSPLIT, EPI, BN, 2>(a, stream, splits);
+  return launch2w<NSPLIT, EPI, BN, 4>(a, stream, splits);
 }
 
 
@@ -829,9 +909,15 @@ inline bool fast_ok(int64_t M, int64_t K, int64_t k_len, int passes) {
 
 template <int NSPLIT, int EPI>
 int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
-  if (NSPLIT == 1 && splits == 1 && g_pingpong && !g_force_generic && a.M >= 256 && a.N >= 256 && (a.K % 64) == 0 &&
-      (EPI == VL_EPI_F32 || EPI == VL_EPI_DGELU_BF16 || EPI == VL_EPI_BF16))
-    return launch3<EPI>(a, s);
+  if (splits == 1 && g_pingpong && (NSPLIT == 1 || g_pp3) && !g_force_generic && a.M >= 256 && a.N >= 192 && (a.K % (NSPLIT == 3 ? 32 : 64)) == 0) {
+    // tile width by "rounds over the 256 CUs x width" (key 7: 1 = automatic, 2 / 3 = force 256 / 192)
+    const int64_t tm = (a.M + 255) / 256;
+    const int64_t c256 = ((tm * ((a.N + 255) / 256) + 255) / 256) * 256, c192 = ((tm * ((a.N + 191) / 192) + 255) / 256) * 192;
+    // 1-pass products are the backward dX GEMMs, which share the chip with the dW GEMMs of the side stream: fewer,
+    // wider tiles win there even when they leave CUs to the other stream (A/B in situ: 22.9 vs 23.3 ms / step)
+    const bool wide = g_pingpong == 2 || (g_pingpong != 3 && (c256 <= c192 || (NSPLIT == 1 && g_pingpong == 1 && a.N >= 256)));
+    return wide ? launch3<NSPLIT, EPI, 0>(a, s) : launch3<NSPLIT, EPI, 1>(a, s);
+  }
   if (fast_ok(a.M, a.K, a.k_len, NSPLIT)) {
     switch (pick_bn(a.M, a.N, splits)) {
       case 256: return launch2<NSPLIT, EPI, 256>(a, s, splits);
@@ -963,6 +1049,7 @@ extern "C" int vl_debug_set(int key, int value) {
   else if (key == 4) g_wave_rows = value;
   else if (key == 6) g_ablate = value;
   else if (key == 7) g_pingpong = value;
+  else if (key == 8) g_pp3 = value;
   else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
   return 0;
 }

@@ -54,29 +54,50 @@ def test_gemm_single_pass_bf16(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (300, 260, 192), (1000, 700, 448), (2048, 768, 3072),
                                    (3584, 3072, 768), (513, 257, 2304)])
-def test_gemm_pingpong_kernel(M, N, K):
+@pytest.mark.parametrize("passes,width", [(1, 2), (1, 3), (3, 2), (3, 3)])
+def test_gemm_pingpong_kernel(M, N, K, passes, width):
     """The 8-wave ping-pong kernel behind the 1-pass products (counted vmcnt + staggered barriers): edges, every K-tile
     count parity, and a repeat screen -- the kernel is deterministic, so any run-to-run difference is a staging race."""
     from clg_vqa_amd import _lib
-    a = _rand(M, K, seed=20).to(BF16)
-    b = _rand(N, K, seed=21).to(BF16)
-    ref = (a.double() @ b.double().t()).float()
-    out = torch.full((M, N), float("nan"), device=DEV)
-    ops.gemm_nt(a, None, b, None, M, N, K, 1, EPI_F32, out32=out)
-    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(max(K, 256) / 256))
-    _lib.lib().vl_debug_set(7, 0)  # the older single-barrier kernel computes the same sums in the same k order
+    x, w = _rand(M, K, seed=20), _rand(N, K, seed=21)
+    a, al = _split(x)
+    b, bl = _split(w)
+    if passes == 1:
+        al = bl = None
+        ref = (a.double() @ b.double().t()).float()
+    else:
+        ref = (x.double() @ w.double().t()).float()
+    L = _lib.lib()
     try:
+        L.vl_debug_set(7, width)  # 2: 256 x 256 tiles, 3: 256 x 192 tiles
+        out = torch.full((M, N), float("nan"), device=DEV)
+        ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, out32=out)
+        if passes == 1:  # products of bf16 values are exact in fp32; only the accumulation order differs
+            torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(max(K, 256) / 256))
+        else:            # the dropped lo*lo term: 2^-16 relative per product
+            scale = (x.abs().double() @ w.abs().double().t()).max().item()
+            err = (out.double() - ref.double()).abs().max().item()
+            assert err <= 6e-5 * scale / math.sqrt(K) + 1e-5, (err, scale)
+        filler = torch.empty(64 << 20, device=DEV)
+        for it in range(8):
+            again = torch.full((M, N), float("nan"), device=DEV)
+            filler.normal_()  # evict L2 / perturb timing between runs
+            ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, out32=again)
+            assert torch.equal(again, out), it
+        # the 16-bit epilogue (paired n-tiles, permuted B rows) against the fp32 one
+        sh, sl = torch.empty(M, N, dtype=BF16, device=DEV), torch.empty(M, N, dtype=BF16, device=DEV)
+        ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_SPLIT, out_hi=sh, out_lo=sl)
+        eh, el = _split(out)
+        assert torch.equal(sh, eh) and torch.equal(sl, el)
+        L.vl_debug_set(7, 0)  # the older single-barrier kernel adds the same products in the same k order
         old = torch.empty_like(out)
-        ops.gemm_nt(a, None, b, None, M, N, K, 1, EPI_F32, out32=old)
+        ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, out32=old)
+        if passes == 1:
+            assert torch.equal(out, old)
+        else:
+            torch.testing.assert_close(out, old, rtol=1e-5, atol=1e-5 * math.sqrt(K))
     finally:
-        _lib.lib().vl_debug_set(7, 1)
-    assert torch.equal(out, old)
-    filler = torch.empty(64 << 20, device=DEV)
-    for it in range(12):
-        again = torch.full((M, N), float("nan"), device=DEV)
-        filler.normal_()  # evict L2 / perturb timing between runs
-        ops.gemm_nt(a, None, b, None, M, N, K, 1, EPI_F32, out32=again)
-        assert torch.equal(again, out), it
+        L.vl_debug_set(7, 1)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 200, 264), (1024, 2304, 768), (256, 1842, 768),
@@ -93,7 +114,7 @@ def test_gemm_three_pass_is_fp32_grade(M, N, K):
     ref = (x.double() @ w.double().t() + bias.double() + resid.double())
     err = (out.double() - ref).abs().max().item()
     scale = (x.double().abs() @ w.double().abs().t()).max().item()
-    assert err <= 3e-5 * scale / math.sqrt(K) + 1e-5, (err, scale)
+    assert err <= 6e-5 * scale / math.sqrt(K) + 1e-5, (err, scale)
     # and it is far better than a single bf16 pass
     out1 = torch.empty(M, N, device=DEV)
     ops.gemm_nt(xh, None, wh, None, M, N, K, 1, EPI_F32, bias=bias, resid=resid, out32=out1)

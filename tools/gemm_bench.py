@@ -30,8 +30,8 @@ def main():
     L = _lib.lib()
     shapes = [("qkv   fwd", 14336, 2304, 768), ("oproj fwd", 14336, 768, 768), ("ffn1  fwd", 14336, 3072, 768),
               ("ffn2  fwd", 14336, 768, 3072), ("qkv   dX ", 14336, 768, 2304)]
-    variants = [("bn256-w16", dict(g=0, bn=256, wr=4, pp=0)), ("bn192-w16", dict(g=0, bn=192, wr=4, pp=0)),
-                ("pingpong", dict(g=0, bn=0, wr=4, pp=1))]
+    variants = [("old-256", dict(g=0, bn=256, wr=4, pp=0)), ("old-192", dict(g=0, bn=192, wr=4, pp=0)),
+                ("pp-256", dict(g=0, bn=0, wr=4, pp=2)), ("pp-192", dict(g=0, bn=0, wr=4, pp=3))]
     for passes in (1, 3):
         print("== passes %d ==" % passes)
         for name, M, N, K in shapes:
