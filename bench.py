@@ -39,11 +39,16 @@ def uc2_full_cfg():
 
 
 class GemmTimer(object):
-    """HIP-event pairs around launches of the dominant kernel, on the stream they are launched on."""
+    """HIP-event pairs around launches of the dominant kernel, on the stream they are launched on.  Every STRIDE-th
+    launch of the timed region is bracketed (an event pair costs ~12 us of host time and a bubble on the stream; timing
+    all 84 GEMMs of a step made the step 4 % slower than it is).  84 launches per step and STRIDE = 5 are co-prime, so
+    over the timed steps every GEMM of the step is sampled equally often."""
+    STRIDE = 5
 
     def __init__(self):
         self.records = []  # (passes, flops, ev0, ev1)
         self.enabled = False
+        self.count = 0
 
     def wrap(self, ops_mod):
         inner = ops_mod.gemm_nt
@@ -51,6 +56,9 @@ class GemmTimer(object):
 
         def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw):
             if not timer.enabled:
+                return inner(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw)
+            timer.count += 1
+            if timer.count % timer.STRIDE:
                 return inner(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -70,7 +78,7 @@ class GemmTimer(object):
         return out
 
 
-def pmc_traffic_per_launch(prefix="gemm2_kernel<3,"):
+def pmc_traffic_per_launch(prefix="gemm3_kernel<3,"):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_summary.json,
     produced by tools/profile_summary.py from separate rocprofv3 --pmc passes; FETCH_SIZE doubled for gfx950)."""
     import glob
@@ -204,6 +212,8 @@ def main():
             mask = (torch.rand(w.shape, generator=gen) < 0.59).float().to(dev)
             w.data.mul_(mask)
             prune.CustomFromMask.apply(mods[n], "weight", mask=mask)
+    if os.environ.get("BENCH_GROUP_DW", "0") == "1":  # A/B: one grouped weight-gradient launch per layer
+        model.engine.stack.group_dw = True
     model.train()
     # reference hyper-parameters: experiments/zero_shot/uc2/xgqa/train.dtu.sh:20-28
     opt = FusedAdamW(model, base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True,
@@ -212,10 +222,19 @@ def main():
                                                 seed=1234 + rank))
     crit = torch.nn.CrossEntropyLoss()
 
+    host = [0.0, 0.0, 0.0]  # host-side enqueue seconds (forward, backward, optimizer) -- diagnostics only
+
     def step():
+        c0 = time.perf_counter()
         loss, score = task_utils.ForwardModelsTrain(config, TASK_CFG, dev, "TASK15", batch, model, crit)
+        c1 = time.perf_counter()
         loss.backward()
+        c2 = time.perf_counter()
         opt.step()
+        c3 = time.perf_counter()
+        host[0] += c1 - c0
+        host[1] += c2 - c1
+        host[2] += c3 - c2
         return loss
 
     for _ in range(args.warmup):
@@ -223,7 +242,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
+    timer.enabled = os.environ.get("BENCH_NO_GEMM_TIMER", "0") != "1"
+    host[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -238,6 +258,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.detach())
+    if rank == 0:
+        print("[bench] host enqueue per step: fwd %.2f ms, bwd %.2f ms, opt %.2f ms" % tuple(1e3 * h / args.steps for h in host),
+              file=sys.stderr, flush=True)
 
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
@@ -245,13 +268,13 @@ def main():
         roof = None
         if 3 in gs:
             ach = gs[3]["flops"] / (gs[3]["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="gemm2_kernel<3,*> (forward GEMMs, 3-pass split bf16 MFMA)", achieved=round(ach, 2),
+            roof = dict(bound="mfma", kernel="gemm3_kernel<3,*> (forward GEMMs, 3-pass split bf16 MFMA, 8-wave ping-pong)", achieved=round(ach, 2),
                         peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         traffic=pmc_traffic_per_launch(), algorithmic_bytes_per_launch=None, mfma_passes=3, mfma_issue_frac=round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         launches=gs[3]["launches"], avg_launch_us=round(1e3 * gs[3]["ms"] / gs[3]["launches"], 2))
             if 1 in gs:
                 a1 = gs[1]["flops"] / (gs[1]["ms"] * 1e-3) / 1e12
-                roof["backward_gemm"] = dict(kernel="gemm2_kernel<1,*> (backward dX GEMMs, bf16 MFMA)", achieved=round(a1, 2),
+                roof["backward_gemm"] = dict(kernel="gemm3_kernel<1,*> (backward dX GEMMs, bf16 MFMA, 8-wave ping-pong)", achieved=round(a1, 2),
                                              frac=round(a1 / MFMA_BF16_PEAK_TFLOPS, 4), launches=gs[1]["launches"],
                                              avg_launch_us=round(1e3 * gs[1]["ms"] / gs[1]["launches"], 2))
         line = {

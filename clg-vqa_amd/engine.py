@@ -139,6 +139,7 @@ class LayerStack(object):
         # weight-gradient GEMMs (dW = dY^T X, bias column sums) are off the backward critical path: they run on a
         # second HIP stream so that their workgroups fill the CUs the dX / LayerNorm / attention kernels leave idle
         self.overlap_dw = True
+        self.group_dw = False  # one grouped launch per layer (ops.gemm_tn_grouped): measured equal in situ, see DESIGN.md
         self._side = None
 
     def make_prepared(self, device):
@@ -189,6 +190,8 @@ class LayerStack(object):
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
         keep = []  # operands of side-stream kernels stay referenced until the streams are joined
+        # one grouped weight-gradient launch per layer needs B*S % 64 == 0 and 8-aligned feature sizes
+        grouped = self.group_dw and M % 64 == 0 and H % 8 == 0 and I % 8 == 0
 
         def on_side(fn, *tensors):
             """Run fn (weight-gradient work) on the side stream after everything enqueued so far on the main one."""
@@ -209,17 +212,19 @@ class LayerStack(object):
                        ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
             du16 = b16(M, I)
             ops.gemm_nt(dt2, None, lw["w2"].t_hi, None, M, I, H, 1, EPI_DGELU_BF16, out_hi=du16, aux16=ls["u16"])
-            dW2, dW1, dbias1 = on_side(lambda: (_masked(dw_gemm(dt2, ls["h_hi"], M, H, I), sp.w2),
-                                                _masked(dw_gemm(du16, ls["x1_hi"], M, I, H), sp.w1),
-                                                ops.colsum_bf16(du16, M, I, f32(I))),
-                                       dt2, du16, ls["h_hi"], ls["x1_hi"])
+            if not grouped:
+                dW2, dW1, dbias1 = on_side(lambda: (_masked(dw_gemm(dt2, ls["h_hi"], M, H, I), sp.w2),
+                                                    _masked(dw_gemm(du16, ls["x1_hi"], M, I, H), sp.w1),
+                                                    ops.colsum_bf16(du16, M, I, f32(I))),
+                                           dt2, du16, ls["h_hi"], ls["x1_hi"])
             dx1 = f32(M, H)
             ops.gemm_nt(du16, None, lw["w1"].t_hi, None, M, H, I, 1, EPI_F32, resid=dz2, out32=dx1)
             dz1, dt1 = f32(M, H), b16(M, H)
             dg1, db1, dbias_o = f32(H), f32(H), f32(H)
             ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, dg1, db1,
                        dbias_o, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
-            dWo = on_side(lambda: _masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), sp.o), dt1, ls["ctx_hi"])
+            if not grouped:
+                dWo = on_side(lambda: _masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), sp.o), dt1, ls["ctx_hi"])
             dctx = f32(M, H)
             ops.gemm_nt(dt1, None, lw["o"].t_hi, None, M, H, H, 1, EPI_F32, out32=dctx)
             dqkv = b16(M, 3 * H)
@@ -232,7 +237,23 @@ class LayerStack(object):
                     _masked(dW[i * H:(i + 1) * H], lin)
                 return dW, ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H))
 
-            dWqkv, dbqkv = on_side(qkv_grads, dqkv, ls["x_hi"])
+            def layer_grads_grouped():
+                # the layer's six weight gradients in ONE launch (no split-K slabs); SFT masks ride in the epilogue
+                dWqkv, dWo, dW1, dW2 = f32(3 * H, H), f32(H, H), f32(I, H), f32(H, I)
+                mk = lambda lin: linear_params(lin)[1]  # noqa: E731
+                probs = [(dqkv[:, i * H:(i + 1) * H], ls["x_hi"], dWqkv[i * H:(i + 1) * H], mk(lin))
+                         for i, lin in enumerate((sp.q, sp.k, sp.v))]
+                probs += [(dt1, ls["ctx_hi"], dWo, mk(sp.o)), (du16, ls["x1_hi"], dW1, mk(sp.w1)),
+                          (dt2, ls["h_hi"], dW2, mk(sp.w2))]
+                ops.gemm_tn_grouped(probs, M)
+                return (dWqkv, ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H)), dWo, dW1,
+                        ops.colsum_bf16(du16, M, I, f32(I)), dW2)
+
+            if grouped:
+                dWqkv, dbqkv, dWo, dW1, dbias1, dW2 = on_side(layer_grads_grouped, dqkv, dt1, du16, dt2, ls["x_hi"],
+                                                              ls["ctx_hi"], ls["x1_hi"], ls["h_hi"])
+            else:
+                dWqkv, dbqkv = on_side(qkv_grads, dqkv, ls["x_hi"])
             dx0 = f32(M, H)
             ops.gemm_nt(dqkv, None, lw["qkv"].t_hi, None, M, H, 3 * H, 1, EPI_F32, resid=dz1, out32=dx0)
             layer_grads[l] = [dWqkv[0:H], dbqkv[0:H], dWqkv[H:2 * H], dbqkv[H:2 * H], dWqkv[2 * H:], dbqkv[2 * H:],

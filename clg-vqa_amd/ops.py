@@ -85,6 +85,24 @@ def gemm_tn_splitk(a, b, M, N, K, out32, splits=None):
     return True
 
 
+def gemm_tn_grouped(problems, K, splits=0):
+    """One launch for several weight-gradient products sharing the batch dimension K:
+    problems = [(a [K,M] bf16, b [K,N] bf16, out [M,N] fp32, mask [M,N] fp32 or None), ...]  ->  out = a^T b (* mask)."""
+    import ctypes
+    n = len(problems)
+    arr = (ctypes.c_int64 * (10 * n))()
+    for i, (a, b, out, mask) in enumerate(problems):
+        pa, lda = _pld(a)
+        pb, ldb = _pld(b)
+        M, N = a.shape[1], b.shape[1]
+        assert a.shape[0] == K and b.shape[0] == K and tuple(out.shape) == (M, N) and out.stride(1) == 1
+        assert out.dtype == torch.float32 and (mask is None or (mask.dtype == torch.float32 and mask.stride() == out.stride()))
+        arr[10 * i:10 * i + 10] = [pa or 0, lda, pb or 0, ldb, out.data_ptr(), out.stride(0),
+                                   0 if mask is None else mask.data_ptr(), M, N, 0]
+    _lib.check(_lib.lib().vl_gemm_tn_grouped(ctypes.cast(arr, ctypes.c_void_p), n, K, splits, _stream()),
+               "vl_gemm_tn_grouped")
+
+
 def attn_fwd(qkv32, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed):
     _lib.check(_lib.lib().vl_attn_fwd(_p(qkv32), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
                                       float(p_drop), int(seed), _stream()), "vl_attn_fwd")

@@ -64,6 +64,18 @@ int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi, int64_t l
 int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float* ws, float* out32, void* stream);
 
+/* Grouped form of the same product (the four dW GEMMs of one transformer layer in ONE launch, no split-K slabs):
+ * for each problem p, out_p[M_p, N_p] = A_p^T B_p (* mask_p) with A_p [K, M_p], B_p [K, N_p] row-major bf16 and K
+ * (the batch rows, a multiple of 64) shared.  `probs` is a HOST array of nprob x VL_TN_FIELDS int64 values
+ * {a, lda, b, ldb, out, ldo, mask (0 = none; fp32, same layout as out), M, N, 0}; M, N multiples of 8, nprob <= 8.
+ * splits: 1 = one workgroup per 256 x 256 output tile; 2 = two K-halves atomically added into the (zeroed here)
+ * output -- exactly two addends per element, so the sum is still deterministic; 0 = pick by tile count.
+ * Replaces autograd's grad_weight = grad_output.t() @ input of nn.Linear (volta/encoders.py:229-246, 411-414,
+ * 496-501, 553-556) and, with `mask`, the grad(weight_orig) = grad(weight) * weight_mask product of
+ * torch.nn.utils.prune under train_task_sft.py:128-132. */
+#define VL_TN_FIELDS 10
+int vl_gemm_tn_grouped(const int64_t* probs, int64_t nprob, int64_t K, int64_t splits, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused V&L attention core over the single stream X = [text ; boxes]  (S = T + V <= 160, head dim 64).
  * Replaces encoders.py:255-341: four gated score blocks, two concatenated softmaxes, four dropouts, four P.V

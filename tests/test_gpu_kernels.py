@@ -449,3 +449,34 @@ def test_adamw_untouched_row_fast_path_is_bit_identical():
         res.append((p, m, v))
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("K,splits", [(64, 1), (448, 1), (1024, 2), (14336, 0)])
+def test_gemm_tn_grouped(K, splits):
+    """Several dW = dY^T X products in one launch (ping-pong kernel with transposing LDS reads), masks in the epilogue."""
+    shapes = [(768, 768), (264, 136), (16, 520), (776, 1032)] if K < 2000 else [(768, 768), (2304, 768), (768, 3072)]
+    g = torch.Generator(device="cpu").manual_seed(K)
+    probs, refs = [], []
+    for i, (M, N) in enumerate(shapes):
+        wide = _rand(K, M + 24, seed=50 + i).to(BF16)
+        a = wide[:, 8:8 + M]  # a column slice: lda > M
+        b = _rand(K, N, seed=60 + i).to(BF16)
+        mask = (torch.rand(M, N, generator=g) > 0.3).float().to(DEV) if i % 2 == 0 else None
+        out = torch.full((M, N), float("nan"), device=DEV)
+        probs.append((a, b, out, mask))
+        ref = a.double().t() @ b.double()
+        refs.append((ref * mask.double() if mask is not None else ref).float())
+    ops.gemm_tn_grouped(probs, K, splits)
+    for (a, b, out, mask), ref in zip(probs, refs):
+        torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(max(K, 256) / 256))
+    first = [p[2].clone() for p in probs]
+    filler = torch.empty(64 << 20, device=DEV)
+    for it in range(6):  # deterministic (also with the two atomically added K-halves): any difference is a staging race
+        for p in probs:
+            p[2].fill_(float("nan"))
+        filler.normal_()
+        ops.gemm_tn_grouped(probs, K, splits)
+        for p, f in zip(probs, first):
+            assert torch.equal(p[2], f), it
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm_tn_grouped([(probs[0][0][:40], probs[0][1][:40], probs[0][2], None)], 40)

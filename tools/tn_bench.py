@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Stand-alone timing of one layer's weight-gradient products: grouped ping-pong launch vs the per-product split-K path."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from clg_vqa_amd import ops  # noqa: E402
+from clg_vqa_amd.engine import dw_gemm  # noqa: E402
+
+BF16 = torch.bfloat16
+
+
+def bench(fn, iters=10):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def main():
+    K, H, I = 14336, 768, 3072
+    dev = "cuda"
+    dqkv, dt1, du16, dt2 = [torch.randn(K, n, device=dev).to(BF16) for n in (3 * H, H, I, H)]
+    x, ctx, x1, h = [torch.randn(K, n, device=dev).to(BF16) for n in (H, H, H, I)]
+    outs = [torch.empty(3 * H, H, device=dev), torch.empty(H, H, device=dev), torch.empty(I, H, device=dev),
+            torch.empty(H, I, device=dev)]
+    probs = [(dqkv[:, i * H:(i + 1) * H], x, outs[0][i * H:(i + 1) * H], None) for i in range(3)]
+    probs += [(dt1, ctx, outs[1], None), (du16, x1, outs[2], None), (dt2, h, outs[3], None)]
+    flops = 2.0 * K * (3 * H * H + H * H + 2 * I * H)
+    for splits in (1, 2):
+        us = bench(lambda: ops.gemm_tn_grouped(probs, K, splits))
+        print("grouped splits=%d: %.1f us  %.0f TF" % (splits, us, flops / us / 1e6))
+    for i, p in enumerate(probs):
+        f = 2.0 * K * p[0].shape[1] * p[1].shape[1]
+        us = bench(lambda: ops.gemm_tn_grouped([p], K, 1))
+        print("  problem %d alone (%d tiles): %.1f us %.0f TF" % (i, ((p[0].shape[1] + 255) // 256) * ((p[1].shape[1] + 255) // 256), us, f / us / 1e6))
+
+    def old():
+        dw_gemm(dqkv, x, K, 3 * H, H)
+        dw_gemm(dt1, ctx, K, H, H)
+        dw_gemm(du16, x1, K, I, H)
+        dw_gemm(dt2, h, K, H, I)
+    us = bench(old)
+    print("per-product split-K: %.1f us  %.0f TF" % (us, flops / us / 1e6))
+
+
+if __name__ == "__main__":
+    main()
