@@ -29,7 +29,9 @@ extern "C" {
 
 int vl_version(void);
 const char* vl_last_error(void);
-int vl_debug_set(int key, int value); /* benchmarking knobs: 1 = force GEMM tile BN (0 auto), 2 = force generic GEMM */
+int vl_debug_set(int key, int value); /* A/B knobs for benchmarking (not part of the drop-in surface): 1 = BN of the
+                                         single-barrier GEMM, 2 = force the generic GEMM, 7 = ping-pong GEMM (0 off, 1 auto,
+                                         2/3 = 256/192-wide tiles), 8 = ping-pong for 3-pass products */
 
 /* ------------------------------------------------------------------------------------------------------------
  * GEMM  C[M,N] = A[M,K] * B[N,K]^T  (+ epilogue), bf16 MFMA with fp32 accumulation.

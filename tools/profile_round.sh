@@ -1,18 +1,18 @@
 #!/bin/bash
-# Round profile on the GPU box: kernel-trace stats + three separate PMC passes (never combined with other traces),
-# condensed into profiles/<round>_*.  Usage: bash tools/profile_round.sh r01
-set -e
+# Round profile on the GPU box: kernel-trace stats + separate PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one
+# pass on gfx950; counters are never combined with other trace domains), condensed into gpurun_out/<round>/summary.
+# Usage: bash tools/profile_round.sh r01      (then copy gpurun_out/r01/summary/* into profiles/)
 R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$R
 rm -rf $OUT && mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1
-echo "stats done" 
-rocprofv3 --pmc FETCH_SIZE WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc1 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc1.log 2>&1
-echo "pmc1 done"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc2 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc2.log 2>&1
-echo "pmc2 done"
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT/pmc3 -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc3.log 2>&1
-echo "pmc3 done"
-python3 tools/profile_summary.py --round $R --stats $OUT/stats --steps 4 --pmc $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 --out $OUT/summary
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -3 $OUT/stats.log; exit 1; }
+echo "stats done"
+i=0
+for ctr in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
+  i=$((i+1))
+  timeout -k 10 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i ($ctr) failed"; grep -m3 -i "error\|fail" $OUT/pmc$i.log; exit 1; }
+  echo "pmc$i ($ctr) done"
+done
+python3 tools/profile_summary.py --round $R --stats $OUT/stats --steps 4 --pmc $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 --out $OUT/summary
 ls -la $OUT/summary
