@@ -127,6 +127,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int nt = 0; nt < NT; ++nt)
           sc[nt] = mfma4(qa[ks], sK[(nt * 16 + i16) * LDK + 16 * k4 + ks], sc[nt]);
       }
+      // dropout keep-scales: one hash per (4 consecutive queries, key) = the 4 accumulator registers of a lane
+      float kp[NT][4];
+      if (p.p_drop > 0.f) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          vl_dropout_scale4(p.seed, (((uint64_t)b * p.nh + h) * ((S + 3) >> 2) + (qt * 4 + k4)) * S + nt * 16 + i16,
+                            p.p_drop, p.inv_keep, kp[nt]);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ql = 4 * k4 + r, q = qt * 16 + ql;
@@ -150,8 +158,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int nt = 0; nt < NT; ++nt) {
           const int key = nt * 16 + i16;
           float pv = sc[nt][r] * inv;
-          if (p.p_drop > 0.f && q < S && key < S)
-            pv *= vl_dropout_scale(p.seed, (((uint64_t)b * p.nh + h) * S + q) * S + key, p.p_drop, p.inv_keep);
+          if (p.p_drop > 0.f && q < S && key < S) pv *= kp[nt][r];
           sP[ql * LDP + key] = pv;
         }
       }
@@ -277,13 +284,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
           dp = mfma4(sdO[i16 * LDT + 4 * ks + k4], sV[(kt * 16 + i16) * LDT + 4 * ks + k4], dp);
         }
         const int key = kt * 16 + i16;
+        float kp[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if (p.p_drop > 0.f)  // the forward pass's keep-scales (same hash grouping: 4 consecutive queries of one key)
+          vl_dropout_scale4(p.seed, (((uint64_t)b * p.nh + h) * ((S + 3) >> 2) + (qt * 4 + k4)) * S + key, p.p_drop,
+                            p.inv_keep, kp);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ql = 4 * k4 + r, q = qt * 16 + ql;
           const float pr = __expf(s[r] * p.scale + smask[key] - slse[ql]);
           float dsc = 1.0f;
-          if (p.p_drop > 0.f && q < S && key < S)
-            dsc = vl_dropout_scale(p.seed, (((uint64_t)b * p.nh + h) * S + q) * S + key, p.p_drop, p.inv_keep);
+          if (p.p_drop > 0.f && q < S && key < S) dsc = kp[r];
           sPd[ql * LDP + key] = pr * dsc;
           sdS[ql * LDP + key] = pr * (dsc * dp[r] - sdelta[ql]) * p.scale;
         }

@@ -72,6 +72,23 @@ __device__ __forceinline__ float vl_dropout_scale(uint64_t seed, uint64_t idx, f
   return u >= p ? inv_keep : 0.0f;
 }
 
+// Four keep-scales from ONE 64-bit draw: element t of the aligned group `gidx` uses bits [16t, 16t+16) of the hash
+// (drop probability quantised to 1/65536).  A lane of the LayerNorm kernels holds 4 consecutive elements of a row and
+// a lane of the attention kernels 4 consecutive queries of one key, so this is one splitmix64 (~25 VALU ops, most of the
+// per-element work of the attention soft-max loop) per 4 elements instead of per element.
+__device__ __forceinline__ void vl_dropout_scale4(uint64_t seed, uint64_t gidx, float p, float inv_keep, float s[4]) {
+  uint64_t z = seed + gidx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  const uint32_t thr = (uint32_t)(p * 65536.0f + 0.5f);
+  const uint32_t lo = (uint32_t)z, hi = (uint32_t)(z >> 32);
+  s[0] = (lo & 0xFFFFu) >= thr ? inv_keep : 0.0f;
+  s[1] = (lo >> 16) >= thr ? inv_keep : 0.0f;
+  s[2] = (hi & 0xFFFFu) >= thr ? inv_keep : 0.0f;
+  s[3] = (hi >> 16) >= thr ? inv_keep : 0.0f;
+}
+
 // ---- wave reductions (64 lanes) ------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -46,10 +46,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
       const long e = r * p.H + c;
       float4 v = *reinterpret_cast<const float4*>(p.y + e);
       if (p.p_pre > 0.f) {
-        v.x *= vl_dropout_scale(p.seed, e + 0, p.p_pre, p.inv_pre);
-        v.y *= vl_dropout_scale(p.seed, e + 1, p.p_pre, p.inv_pre);
-        v.z *= vl_dropout_scale(p.seed, e + 2, p.p_pre, p.inv_pre);
-        v.w *= vl_dropout_scale(p.seed, e + 3, p.p_pre, p.inv_pre);
+        float ks_[4];
+        vl_dropout_scale4(p.seed, (uint64_t)e >> 2, p.p_pre, p.inv_pre, ks_);
+        v.x *= ks_[0]; v.y *= ks_[1]; v.z *= ks_[2]; v.w *= ks_[3];
       }
       if (p.resid) {
         const float4 q = *reinterpret_cast<const float4*>(p.resid + e);
@@ -89,10 +88,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
       o.w = g.w * ((z[i].w - mu) * rs) + bt.w;
       if (p.p_post > 0.f) {
         const long e = r * p.H + c;
-        o.x *= vl_dropout_scale(p.seed ^ POST_SALT, e + 0, p.p_post, p.inv_post);
-        o.y *= vl_dropout_scale(p.seed ^ POST_SALT, e + 1, p.p_post, p.inv_post);
-        o.z *= vl_dropout_scale(p.seed ^ POST_SALT, e + 2, p.p_post, p.inv_post);
-        o.w *= vl_dropout_scale(p.seed ^ POST_SALT, e + 3, p.p_post, p.inv_post);
+        float ks_[4];
+        vl_dropout_scale4(p.seed ^ POST_SALT, (uint64_t)e >> 2, p.p_post, p.inv_post, ks_);
+        o.x *= ks_[0]; o.y *= ks_[1]; o.z *= ks_[2]; o.w *= ks_[3];
       }
       if (p.row_post) {
         const float rq = p.row_post[r];
@@ -130,10 +128,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
       const long e = r * p.H + c;
       float4 d = *reinterpret_cast<const float4*>(p.dy + orow * p.H + c);
       if (p.p_post > 0.f) {
-        d.x *= vl_dropout_scale(p.seed ^ POST_SALT, e + 0, p.p_post, p.inv_post);
-        d.y *= vl_dropout_scale(p.seed ^ POST_SALT, e + 1, p.p_post, p.inv_post);
-        d.z *= vl_dropout_scale(p.seed ^ POST_SALT, e + 2, p.p_post, p.inv_post);
-        d.w *= vl_dropout_scale(p.seed ^ POST_SALT, e + 3, p.p_post, p.inv_post);
+        float ks_[4];
+        vl_dropout_scale4(p.seed ^ POST_SALT, (uint64_t)e >> 2, p.p_post, p.inv_post, ks_);
+        d.x *= ks_[0]; d.y *= ks_[1]; d.z *= ks_[2]; d.w *= ks_[3];
       }
       if (p.row_post) {
         const float rq = p.row_post[r];
@@ -167,10 +164,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
       if (p.dz) *reinterpret_cast<float4*>(p.dz + e) = dz;
       float4 dp = dz;
       if (p.p_pre > 0.f) {
-        dp.x *= vl_dropout_scale(p.seed, e + 0, p.p_pre, p.inv_pre);
-        dp.y *= vl_dropout_scale(p.seed, e + 1, p.p_pre, p.inv_pre);
-        dp.z *= vl_dropout_scale(p.seed, e + 2, p.p_pre, p.inv_pre);
-        dp.w *= vl_dropout_scale(p.seed, e + 3, p.p_pre, p.inv_pre);
+        float ks_[4];
+        vl_dropout_scale4(p.seed, (uint64_t)e >> 2, p.p_pre, p.inv_pre, ks_);
+        dp.x *= ks_[0]; dp.y *= ks_[1]; dp.z *= ks_[2]; dp.w *= ks_[3];
       }
       if (p.dpre32) *reinterpret_cast<float4*>(p.dpre32 + e) = dp;
       if (p.dpre16) {

@@ -117,11 +117,16 @@ class GradReducer(object):
         """ids [R] int64, rows [R,H] fp32 (this rank's touched rows) -> table_grad += sum over ranks."""
         ws = self.world_size()
         R, H = rows.shape
-        uniq, inv = torch.unique(ids, return_inverse=True)
+        # combine duplicate ids locally with fixed-size ops only (torch.unique would synchronise with the device to
+        # learn its output size): sort, number the runs, add every row into its run's slot
+        sid, order = torch.sort(ids)
+        first = torch.ones(R, dtype=torch.bool, device=ids.device)
+        first[1:] = sid[1:] != sid[:-1]
+        slot = torch.cumsum(first, 0) - 1                       # run index of every sorted position
         comb = torch.zeros(R, H, dtype=rows.dtype, device=rows.device)
-        comb.index_add_(0, inv, rows)
+        comb.index_add_(0, slot, rows.index_select(0, order))
         uid = torch.full((R,), -1, dtype=torch.int64, device=ids.device)
-        uid[:uniq.numel()] = uniq
+        uid.scatter_(0, slot, sid)                              # duplicates write the same value
         if ws > 1:
             all_ids = torch.empty(ws * R, dtype=torch.int64, device=ids.device)
             all_rows = torch.empty(ws * R, H, dtype=rows.dtype, device=rows.device)

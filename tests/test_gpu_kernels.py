@@ -248,8 +248,10 @@ def test_attention_dropout_is_consistent_between_forward_and_backward():
     w = _rand(B * S, H, seed=15)
     dqkv = torch.empty(B * S, 3 * H, dtype=BF16, device=DEV)
     ops.attn_bwd(qkv, addmask, ctx_hi, ctx_lo, w, lse, dqkv, B, S, nh, 64, p, 77)
-    d = _rand(B * S, 3 * H, seed=16)
-    eps = 1e-2
+    # direction aligned with the gradient's signs: no cancellation in <dqkv, d>, so the bf16 rounding of dqkv (2^-9 per
+    # element) cannot masquerade as a mask mismatch
+    d = torch.sign(dqkv.float()) * (0.5 + torch.rand(B * S, 3 * H, generator=torch.Generator().manual_seed(16)).to(DEV))
+    eps = 2e-3
 
     def f(x):
         h_, l_ = torch.empty_like(ctx_hi), torch.empty_like(ctx_hi)
