@@ -199,6 +199,9 @@ class FusedAdamW(object):
         self.arena.grad.zero_()
         for _, p, _, _ in self.groups:
             p.grad = None
+        eng = getattr(self.model, "engine", None)
+        if eng is not None:
+            eng.pending_word_grad = None
 
     def _flag_args(self):
         if self.row_flags is None:

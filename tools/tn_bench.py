@@ -28,8 +28,11 @@ def bench(fn, iters=10):
 def main():
     K, H, I = 14336, 768, 3072
     dev = "cuda"
-    dqkv, dt1, du16, dt2 = [torch.randn(K, n, device=dev).to(BF16) for n in (3 * H, H, I, H)]
-    x, ctx, x1, h = [torch.randn(K, n, device=dev).to(BF16) for n in (H, H, H, I)]
+    pad = int(sys.argv[1]) if len(sys.argv) > 1 else 0   # extra elements in every leading dimension (channel-spread test)
+    mk = lambda n: torch.randn(K, n + pad, device=dev).to(BF16)[:, :n]  # noqa: E731
+    dqkv, dt1, du16, dt2 = [mk(n) for n in (3 * H, H, I, H)]
+    x, ctx, x1, h = [mk(n) for n in (H, H, H, I)]
+    print("leading-dimension pad: %d elements" % pad)
     outs = [torch.empty(3 * H, H, device=dev), torch.empty(H, H, device=dev), torch.empty(I, H, device=dev),
             torch.empty(H, I, device=dev)]
     probs = [(dqkv[:, i * H:(i + 1) * H], x, outs[0][i * H:(i + 1) * H], None) for i in range(3)]
@@ -44,10 +47,11 @@ def main():
         print("  problem %d alone (%d tiles): %.1f us %.0f TF" % (i, ((p[0].shape[1] + 255) // 256) * ((p[1].shape[1] + 255) // 256), us, f / us / 1e6))
 
     def old():
-        dw_gemm(dqkv, x, K, 3 * H, H)
-        dw_gemm(dt1, ctx, K, H, H)
-        dw_gemm(du16, x1, K, I, H)
-        dw_gemm(dt2, h, K, H, I)
+        o = [torch.empty(3 * H, H, device=dev), torch.empty(H, H, device=dev), torch.empty(I, H, device=dev), torch.empty(H, I, device=dev)]
+        ops.gemm_tn_splitk(dqkv, x, 3 * H, H, K, o[0])
+        ops.gemm_tn_splitk(dt1, ctx, H, H, K, o[1])
+        ops.gemm_tn_splitk(du16, x1, I, H, K, o[2])
+        ops.gemm_tn_splitk(dt2, h, H, I, K, o[3])
     us = bench(old)
     print("per-product split-K: %.1f us  %.0f TF" % (us, flops / us / 1e6))
 
