@@ -68,10 +68,12 @@ class PreparedWeight(object):
             r += n
         return rows
 
-    def refresh_bias(self):
+    def refresh_bias(self, fingerprint=True):
         self.bias = (self.linears[0].bias.detach() if len(self.linears) == 1
                      else torch.cat([l.bias.detach() for l in self.linears]))
-        self.key = self._key()
+        # after an explicit mark_dirty() the version fingerprint is left empty: the next call that is not preceded by
+        # an optimizer step sees a mismatch, prepares once more and records the real fingerprint
+        self.key = self._key() if fingerprint else None
 
     def refresh(self, force=False):
         key = self._key()
@@ -89,6 +91,11 @@ class PreparedWeight(object):
         self.key = key
 
 
+def _src_ptrs(lin):
+    w, m = linear_params(lin)
+    return (w.data_ptr(), 0 if m is None else m.data_ptr())
+
+
 def dw_gemm(dy16, x16, M, N, K):
     """dW[N,K] = dY[M,N]^T . X[M,K] (bf16 operands, fp32 out) as an NT GEMM over transposed copies."""
     dev = dy16.device
@@ -97,8 +104,8 @@ def dw_gemm(dy16, x16, M, N, K):
         return dW
     Mp = _ceil8(M)
     alloc = torch.zeros if Mp != M else torch.empty
-    dyT = alloc(N, Mp, dtype=BF16, device=dev)
-    xT = alloc(K, Mp, dtype=BF16, device=dev)
+    dyT = ops._tmp(alloc(N, Mp, dtype=BF16, device=dev))
+    xT = ops._tmp(alloc(K, Mp, dtype=BF16, device=dev))
     ops.transpose_bf16(dy16, dyT, M, N)
     ops.transpose_bf16(x16, xT, M, K)
     ops.gemm_nt_splitk(dyT, xT, N, K, Mp, dW)
@@ -139,6 +146,7 @@ class LayerStack(object):
         # weight-gradient GEMMs (dW = dY^T X, bias column sums) are off the backward critical path: they run on a
         # second HIP stream so that their workgroups fill the CUs the dX / LayerNorm / attention kernels leave idle
         self.overlap_dw = True
+        self._fork = None
         self.group_dw = False  # one grouped launch per layer (ops.gemm_tn_grouped): measured equal in situ, see DESIGN.md
         self._side = None
 
@@ -193,16 +201,26 @@ class LayerStack(object):
         # one grouped weight-gradient launch per layer needs B*S % 64 == 0 and 8-aligned feature sizes
         grouped = self.group_dw and M % 64 == 0 and H % 8 == 0 and I % 8 == 0
 
+        main_ptr = main.cuda_stream
+        side_ptr = side.cuda_stream if side is not None else None
+        if self._fork is None:
+            self._fork = torch.cuda.Event()  # re-recorded for every fork: a wait captures the record enqueued before it
+
         def on_side(fn, *tensors):
-            """Run fn (weight-gradient work) on the side stream after everything enqueued so far on the main one."""
+            """Run fn (weight-gradient work) on the side stream after everything enqueued so far on the main one.
+            torch's current stream stays the main one (no stream context switch: ~30 us each): the launches are routed
+            by handle, results are allocated from the main stream's pool and only consumed after the join, operands
+            and wrapper temporaries stay referenced in `keep` until then."""
             if side is None:
                 return fn()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
+            self._fork.record(main)
+            side.wait_event(self._fork)
             keep.extend(tensors)
-            with torch.cuda.stream(side):
+            ops.set_stream(side_ptr, hold=keep)
+            try:
                 return fn()
+            finally:
+                ops.set_stream(main_ptr)
 
         for l in reversed(range(len(self.specs))):
             sp, lw, ls = self.specs[l], pw_layers[l], saved[l]
@@ -312,19 +330,20 @@ class EngineBase(object):
             self._dirty = True
         pw = self._prepared
         all_pw = [pw["img"]] + [lw[k] for lw in pw["layers"] for k in ("qkv", "o", "w1", "w2")]
-        if self._dirty or any(p._key() != p.key for p in all_pw):
-            desc = [r for p in all_pw for r in p.descriptors()]
-            ident = tuple((r[0], r[1]) for r in desc)
+        explicit = self._dirty  # set by the optimizer every step: no need to fingerprint versions to find that out
+        if explicit or any(p._key() != p.key for p in all_pw):
+            # the device table only depends on where the source weights / masks live: compare those pointers first
+            ident = tuple(q for p in all_pw for l in p.linears for q in _src_ptrs(l))
             if pw.get("table_ident") != ident:
                 rows, tile0 = [], 0
-                for r in desc:
+                for r in (r for p in all_pw for r in p.descriptors()):
                     rows.append(r + [tile0])
                     tile0 += ((r[5] + 63) // 64) * ((r[6] + 63) // 64)
                 pw["table"] = torch.tensor(rows, dtype=torch.int64).to(device)
                 pw["table_ident"], pw["table_tiles"] = ident, tile0
             ops.weight_prep_multi(pw["table"], pw["table"].shape[0], pw["table_tiles"])  # one launch per step
             for p in all_pw:
-                p.refresh_bias()
+                p.refresh_bias(fingerprint=not explicit)
         self._dirty = False
         return pw
 
@@ -482,14 +501,22 @@ class TrunkFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, training, ids, feats, locs, seg, tmask, imask, *params):
-        out, sv = engine.forward(ids, feats, locs, seg, tmask, imask, training)
+        ops.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream lookup for all launches of the pass
+        try:
+            out, sv = engine.forward(ids, feats, locs, seg, tmask, imask, training)
+        finally:
+            ops.set_stream(None)
         ctx.engine = engine
         ctx.sv = sv
         return out
 
     @staticmethod
     def backward(ctx, dx):
-        grads = ctx.engine.backward(ctx.sv, dx)
+        ops.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            grads = ctx.engine.backward(ctx.sv, dx)
+        finally:
+            ops.set_stream(None)
         ctx.sv = None
         needs = ctx.needs_input_grad[8:]
         grads = [g if need else None for g, need in zip(grads, needs)]

@@ -286,9 +286,12 @@ class M3PForVLTasks(PreTrainedModel):
 
     def mark_weights_dirty(self):
         self._engine.mark_dirty()
-        for m in self.modules():
-            if isinstance(m, VLLinear):
-                object.__setattr__(m, "_vl_dirty", True)
+        lins = self.__dict__.get("_vl_linears")
+        if lins is None:
+            lins = [m for m in self.modules() if isinstance(m, VLLinear)]
+            object.__setattr__(self, "_vl_linears", lins)
+        for m in lins:
+            object.__setattr__(m, "_vl_dirty", True)
 
     def forward(self, input_txt, input_imgs, image_loc, task_id, token_type_ids=None, attention_mask=None,
                 image_attention_mask=None, output_all_encoded_layers=False, output_all_attention_masks=False):

@@ -1,5 +1,7 @@
 """Thin tensor-level wrappers over the C ABI (include/vlhip.h).  Tensors are torch CUDA(=HIP) tensors used
 purely as device-memory handles; every op enqueues on torch's current stream.  CPU tensors are rejected."""
+import threading
+
 import torch
 
 from . import _lib
@@ -8,8 +10,32 @@ BF16 = torch.bfloat16
 EPI_F32, EPI_GELU_SPLIT, EPI_DGELU_BF16, EPI_BF16, EPI_SPLIT = 0, 1, 2, 3, 4
 
 
+class _Launch(threading.local):
+    """Per-thread launch context.  `stream`: explicit HIP stream handle for every native launch (the engine sets it
+    once per forward / backward: torch.cuda.current_stream() costs ~9 us per call, i.e. ~1 ms per step); `hold`: while
+    launches go to a stream other than torch's current one, temporaries allocated inside the wrappers are appended
+    here so that the caching allocator cannot hand their memory out again before the streams are joined."""
+    stream = None
+    hold = None
+
+
+_launch = _Launch()
+
+
+def set_stream(handle, hold=None):
+    """Route the native launches of this thread to `handle` (None = torch's current stream again)."""
+    _launch.stream, _launch.hold = handle, hold
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    s = _launch.stream
+    return s if s is not None else torch.cuda.current_stream().cuda_stream
+
+
+def _tmp(t):
+    if _launch.hold is not None:
+        _launch.hold.append(t)
+    return t
 
 
 def _p(t):
@@ -58,7 +84,7 @@ def gemm_nt_splitk(a_hi, b_hi, M, N, K, out32, splits=None):
         splits = L.vl_gemm_splitk_plan(M, N, K)
     ws = None
     if splits > 1:
-        ws = torch.empty(L.vl_gemm_splitk_ws_floats(M, N, splits), dtype=torch.float32, device=out32.device)
+        ws = _tmp(torch.empty(L.vl_gemm_splitk_ws_floats(M, N, splits), dtype=torch.float32, device=out32.device))
     pa, lda = _pld(a_hi)
     pb, ldb = _pld(b_hi)
     assert out32.is_contiguous() and out32.shape[-1] == N
@@ -74,7 +100,7 @@ def gemm_tn_splitk(a, b, M, N, K, out32, splits=None):
         splits = L.vl_gemm_splitk_plan(M, N, K)
     ws = None
     if splits > 1:
-        ws = torch.empty(L.vl_gemm_splitk_ws_floats(M, N, splits), dtype=torch.float32, device=out32.device)
+        ws = _tmp(torch.empty(L.vl_gemm_splitk_ws_floats(M, N, splits), dtype=torch.float32, device=out32.device))
     pa, lda = _pld(a)
     pb, ldb = _pld(b)
     assert out32.is_contiguous() and out32.shape[-1] == N
@@ -177,7 +203,7 @@ def transpose_bf16(src, dst, M, N):
 
 
 def colsum_bf16(x16, M, N, out32):
-    ws = torch.empty(_lib.lib().vl_colsum_ws_floats(M, N), dtype=torch.float32, device=x16.device)
+    ws = _tmp(torch.empty(_lib.lib().vl_colsum_ws_floats(M, N), dtype=torch.float32, device=x16.device))
     px, ld = _pld(x16)
     _lib.check(_lib.lib().vl_colsum_bf16(px, M, N, ld, _p(ws), _p(out32), _stream()), "vl_colsum_bf16")
     return out32

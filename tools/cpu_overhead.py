@@ -47,3 +47,36 @@ for _ in range(5):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+
+# the trunk's backward runs on autograd's worker thread, which cProfile does not see: call the engine directly
+from clg_vqa_amd import ops  # noqa: E402
+feats, locs, imask, ids, _, tmask, seg = batch[:7]
+eng = model.engine
+
+
+def direct():
+    ops.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        with torch.no_grad():
+            out, sv = eng.forward(ids, feats, locs, seg, tmask, imask, True)
+            eng.backward(sv, torch.ones_like(out))
+    finally:
+        ops.set_stream(None)
+
+
+for _ in range(3):
+    direct()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(10):
+    direct()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+print("engine forward+backward called directly: %.2f ms host time per pass" % ((t1 - t0) / 10 * 1e3))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(5):
+    direct()
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
