@@ -280,9 +280,11 @@ def main():
         loss_, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, dev, "TASK15", batch, model, crit)
         loss_.backward()
     n_extra = max(3, args.steps // 2)
+    opt.set_overlap(False)  # no optimizer step between these backward passes
     fwd_bwd()
     fb_rate = world * args.batch * n_extra / timed(fwd_bwd, n_extra)
     opt.zero_grad()
+    opt.set_overlap(True)
     strong_rate = None
     if world > 1 and args.workload in ("c2", "c3"):
         small = tuple(t.to(dev) for t in make_batch(max(1, 256 // world), num_boxes=num_boxes, num_locs=num_locs,

@@ -146,6 +146,7 @@ class LayerStack(object):
         # weight-gradient GEMMs (dW = dY^T X, bias column sums) are off the backward critical path: they run on a
         # second HIP stream so that their workgroups fill the CUs the dX / LayerNorm / attention kernels leave idle
         self.overlap_dw = True
+        self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
         self._fork = None
         self.group_dw = False  # one grouped launch per layer (ops.gemm_tn_grouped): measured equal in situ, see DESIGN.md
         self._side = None
@@ -276,6 +277,11 @@ class LayerStack(object):
             ops.gemm_nt(dqkv, None, lw["qkv"].t_hi, None, M, H, 3 * H, 1, EPI_F32, resid=dz1, out32=dx0)
             layer_grads[l] = [dWqkv[0:H], dbqkv[0:H], dWqkv[H:2 * H], dbqkv[H:2 * H], dWqkv[2 * H:], dbqkv[2 * H:],
                               dWo, dbias_o, dg1, db1, dW1, dbias1, dW2, dbias2, dg2, db2]
+            if self.layer_done_hook is not None:
+                # multi-GPU: the optimizer takes this layer's gradients now (copy into its flat arena + asynchronous
+                # all-reduce behind the weight-gradient kernels), overlapping the exchange with the rest of backward
+                if on_side(lambda: self.layer_done_hook(l, layer_grads[l], side if side is not None else main)):
+                    layer_grads[l] = [None] * len(layer_grads[l])
             dy = dx0
             saved[l] = None  # release this layer's activations (side-stream operands stay alive through `keep`)
         if side is not None:

@@ -63,13 +63,17 @@ class FlatArena(object):
             p.data = view
         self.grad_views = [self.grad[off:off + p.numel()].view_as(p) for (_, p, _, _), off in zip(groups, offs)]
 
-    def gather_grads(self):
+    def gather_grads(self, pre=()):
         """Copy the autograd-produced gradients into the flat gradient arena (params without a grad -- e.g.
-        M3P's never-used modules -- contribute zeros, like apex skipping ``grad is None``)."""
+        M3P's never-used modules -- contribute zeros, like apex skipping ``grad is None``).  `pre`: indices whose
+        gradient already sits in the arena (written there during backward)."""
         dst, src, has = [], [], []
-        for (_, p, _, _), gv in zip(self.groups, self.grad_views):
-            has.append(p.grad is not None)
+        for i, ((_, p, _, _), gv) in enumerate(zip(self.groups, self.grad_views)):
+            has.append(p.grad is not None or i in pre)
             if p.grad is not None:
+                if i in pre:
+                    raise RuntimeError("clg_vqa_amd.FusedAdamW: parameter %s has an autograd gradient although its "
+                                       "gradient was already reduced during backward" % self.groups[i][0])
                 dst.append(gv)
                 src.append(p.grad)
         if dst:
@@ -98,20 +102,28 @@ class GradReducer(object):
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def allreduce_(self, flat, skip=None):
-        """All-reduce `flat` in buckets; `skip` = (start, end) element range to leave out (sparse segment)."""
+    def allreduce_(self, flat, skip=None, ranges=None):
+        """All-reduce `flat` in buckets; `skip` = (start, end) element range to leave out (sparse segment), or
+        `ranges` = explicit list of (start, end) element ranges to reduce."""
         ws = self.world_size()
         if ws == 1:
             return 1.0
-        ranges = [(0, flat.numel())] if skip is None else [(0, skip[0]), (skip[1], flat.numel())]
+        if ranges is None:
+            ranges = [(0, flat.numel())] if skip is None else [(0, skip[0]), (skip[1], flat.numel())]
+        works = self.allreduce_async(flat, ranges)
+        for w in works:
+            w.wait()
+        return 1.0 / ws
+
+    def allreduce_async(self, flat, ranges):
+        """Enqueue the bucketed all-reduce of the given element ranges; returns the work handles (wait() makes the
+        current stream wait for the collective)."""
         works = []
         for lo, hi in ranges:
             for s in range(lo, hi, self.bucket_elems):
                 works.append(dist.all_reduce(flat[s:min(s + self.bucket_elems, hi)], op=dist.ReduceOp.SUM,
                                              group=self.group, async_op=True))
-        for w in works:
-            w.wait()
-        return 1.0 / ws
+        return works
 
     def exchange_sparse_rows(self, ids, rows, table_grad, scatter_fn):
         """ids [R] int64, rows [R,H] fp32 (this rank's touched rows) -> table_grad += sum over ranks."""
@@ -142,7 +154,7 @@ class FusedAdamW(object):
     """AdamW(correct_bias) + clip + LR schedule + zero-grad as two kernels over the flat arena."""
 
     def __init__(self, model, base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True,
-                 max_grad_norm=1.0, warmup_steps=0, t_total=None, reducer=None):
+                 max_grad_norm=1.0, warmup_steps=0, t_total=None, reducer=None, overlap_reduce=None):
         params = list(model.named_parameters())
         device = params[0][1].device
         if device.type != "cuda":
@@ -179,6 +191,57 @@ class FusedAdamW(object):
                     self.row_flags = torch.zeros(p.shape[0], dtype=torch.uint8, device=device)
                     eng.word_row_flags = self.row_flags
             eng.defer_word_grad = self.reducer.world_size() > 1
+        # multi-GPU: all-reduce each transformer layer's gradients as soon as that layer's backward is enqueued
+        # (needs one optimizer step per backward: pass overlap_reduce=False when accumulating gradients)
+        self._pre, self._works, self._layer_plan = set(), [], None
+        self.keep_reduced_grad = False
+        if overlap_reduce is None:
+            overlap_reduce = self.reducer.world_size() > 1
+        if overlap_reduce and eng is not None and hasattr(eng, "stack"):
+            index_of = {id(g[1]): i for i, g in enumerate(self.groups)}
+            plan = []
+            for sp in eng.stack.specs:
+                idx = [index_of.get(id(p)) for p in sp.params()]
+                if any(i is None for i in idx):  # frozen / foreign parameter in this layer: leave it to step()
+                    plan.append(None)
+                    continue
+                order = sorted(set(idx))
+                ranges, lo, hi, prev = [], None, None, None
+                for i in order:  # merge neighbours in the arena into one range
+                    b = self.arena.offsets[i]
+                    e = b + (self.groups[i][1].numel() + 3) // 4 * 4
+                    if prev is not None and i == prev + 1:
+                        hi = e
+                    else:
+                        if lo is not None:
+                            ranges.append((lo, hi))
+                        lo, hi = b, e
+                    prev = i
+                ranges.append((lo, hi))
+                plan.append((idx, [self.arena.grad_views[i] for i in idx], ranges))
+            self._layer_plan = plan
+            eng.stack.layer_done_hook = self._on_layer_grads
+
+    def set_overlap(self, enabled):
+        """Switch the during-backward gradient exchange on / off (off: everything is reduced inside step())."""
+        eng = getattr(self.model, "engine", None)
+        if eng is not None and hasattr(eng, "stack"):
+            eng.stack.layer_done_hook = self._on_layer_grads if (enabled and self._layer_plan is not None) else None
+
+    def _on_layer_grads(self, layer, grads, stream):
+        plan = self._layer_plan[layer]
+        if plan is None:
+            return False
+        idx, views, ranges = plan
+        if self._pre.intersection(idx):
+            raise RuntimeError("clg_vqa_amd.FusedAdamW: a second backward arrived before step(); construct the optimizer "
+                               "with overlap_reduce=False when accumulating gradients over micro-batches")
+        with torch.cuda.stream(stream):  # behind this layer's weight-gradient kernels
+            torch._foreach_copy_(views, [g.view_as(v) for g, v in zip(grads, views)])
+            if self.reducer.world_size() > 1:
+                self._works += self.reducer.allreduce_async(self.arena.grad, ranges)
+        self._pre.update(idx)
+        return True
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "opt_step": self.opt_step,
@@ -199,6 +262,9 @@ class FusedAdamW(object):
         self.arena.grad.zero_()
         for _, p, _, _ in self.groups:
             p.grad = None
+        for w in self._works:
+            w.wait()
+        self._works, self._pre = [], set()
         eng = getattr(self.model, "engine", None)
         if eng is not None:
             eng.pending_word_grad = None
@@ -218,7 +284,8 @@ class FusedAdamW(object):
     def step(self):
         """reduce -> clip -> AdamW -> scheduler step -> zero_grad  (train_task.py:326-338)."""
         a = self.arena
-        has = a.gather_grads()
+        pre = self._pre
+        has = a.gather_grads(pre)
         # parameters that received no gradient are skipped entirely, like `if p.grad is None: continue` in
         # pytorch_transformers.AdamW (no moment decay, no weight decay): M3P's 93 M never-used parameters
         active = tuple(h or (i == self._sink_index) for i, h in enumerate(has))
@@ -238,7 +305,32 @@ class FusedAdamW(object):
                                                                      row_flags=self.row_flags))
             off = a.offsets[self._sink_index]
             skip = (off, off + (gv.numel() + 3) // 4 * 4)
-        post = self.reducer.allreduce_(a.grad, skip)
+        for w in self._works:  # layer exchanges launched during backward
+            w.wait()
+        self._works = []
+        if self.reducer.world_size() > 1:
+            # whatever was not exchanged during backward: merged ranges of the segments that have a gradient
+            # (skipping e.g. M3P's 93 M never-used parameters and the sparsely exchanged word-embedding table)
+            ranges, lo, hi = [], None, None
+            for i, act in enumerate(active):
+                if not act or i in pre or i == self._sink_index and skip is not None:
+                    continue
+                b = a.offsets[i]
+                e = b + (self.groups[i][1].numel() + 3) // 4 * 4
+                if hi is not None and b == hi:
+                    hi = e
+                else:
+                    if lo is not None:
+                        ranges.append((lo, hi))
+                    lo, hi = b, e
+            if lo is not None:
+                ranges.append((lo, hi))
+            post = self.reducer.allreduce_(a.grad, ranges=ranges)
+        else:
+            post = 1.0
+        self._pre = set()
+        if self.keep_reduced_grad:  # tests: the summed gradient and the 1/world factor the kernels apply to it
+            self.last_reduced_grad, self.last_post = a.grad.clone(), post
         self._sumsq.zero_()
         ops.sumsq(a.grad, self._sumsq)
         # clip coefficient on the device: min(1, max_norm / (||g|| + 1e-6)) with ||g|| of the averaged gradient

@@ -97,3 +97,55 @@ def test_m3p_training_step_skips_unused_parameters():
     assert torch.equal(unused.detach(), u0)       # no gradient -> untouched (no decay), like `if p.grad is None: continue`
     assert not torch.equal(used.detach(), w0)
     assert torch.isfinite(loss)
+
+
+@pytest.mark.parametrize("m3p", [False, True])
+def test_gradient_exchange_during_backward_is_bit_identical_to_the_plain_path(m3p):
+    """FusedAdamW(overlap_reduce=True) takes each layer's gradients during backward (copy into the arena + the
+    asynchronous all-reduce at world size > 1); with one rank the trajectories must be bit-identical, and a second
+    backward before step() must be refused."""
+    from helpers import uc2_cfg_dict
+    from clg_vqa_amd.config import BertConfig
+    from clg_vqa_amd.encoders import BertForVLTasks
+    if m3p:
+        g = load_golden("m3p_small.npz")
+        config = golden_config(g, m3p=True)
+        build = lambda: _build(config, seed=4)[0]  # noqa: E731
+        batch = make_batch(4, num_boxes=36, vocab_size=config.n_words, num_locs=5, l2_normalize=True, seed=5)
+    else:
+        config = BertConfig.from_dict(uc2_cfg_dict(vocab=999, n_layers=2))
+
+        def build():
+            torch.manual_seed(11)
+            return BertForVLTasks(config, TASK_CFG, ["TASK15"]).cuda()
+        batch = make_batch(8, vocab_size=999, seed=6)
+    crit = torch.nn.CrossEntropyLoss()
+    grads, losses = [], []
+    for overlap in (False, True):
+        model = build()
+        model.eval()  # no dropout: both runs see the same function
+        opt = FusedAdamW(model, base_lr=1e-4, weight_decay=0.1, correct_bias=True, max_grad_norm=1.0, overlap_reduce=overlap)
+        assert (model.engine.stack.layer_done_hook is not None) == overlap
+        loss, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, "cuda", "TASK15", batch, model, crit)
+        loss.backward()
+        assert bool(opt._pre) == overlap
+        opt.arena.gather_grads(opt._pre)   # what step() sees: the complete flat gradient
+        torch.cuda.synchronize()
+        grads.append(opt.arena.grad.clone())
+        opt.zero_grad()
+        for _ in range(3):
+            loss, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, "cuda", "TASK15", batch, model, crit)
+            loss.backward()
+            opt.step()
+        losses.append(float(loss))
+        if overlap:
+            loss, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, "cuda", "TASK15", batch, model, crit)
+            loss.backward()
+            loss2, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, "cuda", "TASK15", batch, model, crit)
+            with pytest.raises(RuntimeError, match="second backward"):
+                loss2.backward()
+            opt.zero_grad()
+    # same kernels, same data: equal up to the order of the float atomics in the embedding scatter-adds
+    scale = grads[0].abs().max().item()
+    assert (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
+    assert abs(losses[0] - losses[1]) <= 1e-3 * abs(losses[0])
