@@ -147,7 +147,9 @@ def main(argv=None):
         return FusedAdamW(model, base_lr=base_lr, weight_decay=args.weight_decay, betas=tuple(args.adam_betas),
                           eps=args.adam_epsilon, correct_bias=args.adam_correct_bias,
                           max_grad_norm=args.clip_grad_norm if args.clip_grad_norm > 0 else float("inf"),
-                          warmup_steps=warm, t_total=t_total)
+                          warmup_steps=warm, t_total=t_total,
+                          # gradients are exchanged during backward unless micro-batches are accumulated
+                          overlap_reduce=None if args.grad_acc_steps == 1 else False)
 
     opt = new_optimizer()
     _, global_step, start_epoch, _, max_score = train_utils.resume(args.resume_file, model, opt, None, None)
