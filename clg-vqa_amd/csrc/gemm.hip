@@ -36,6 +36,7 @@ int g_wave_rows = 4;      // 2: 512-thread workgroups (8 waves), 4: 1024-thread 
 int g_alias_rows = 0;
 int g_pingpong = 1;   // 8-wave ping-pong kernel (key 7): 0 = off, 1 = automatic tile width, 2 / 3 = force 256 / 192, 4 = cost model only
 int g_pp3 = 1;        // key 8: 3-pass products on the ping-pong kernel too
+int g_tile224 = 1;    // key 9: allow the 224 x 256 tile
 int g_ablate = 0;     // timing experiment only: A rows wrap modulo this (makes the A operand cache resident)
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -375,7 +376,9 @@ __device__ __forceinline__ int swz3(int row) {
   return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 4) ^ (row >> 2)) & 1) << 2);
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8, "unsupported count");
+  static_assert(N == 0 || N == 3 || N == 4 || N == 5 || N == 6 || N == 7 || N == 8, "unsupported count");
+  if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -385,13 +388,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 template <int NSPLIT, int EPI, int CFG>
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
-  constexpr int WR = CFG == 0 ? 2 : 4, WC = 8 / WR;        // wave grid
-  constexpr int MI = CFG == 0 ? 4 : 2, NJ = CFG == 0 ? 2 : 3;  // 16 x 16 MFMA tiles per quadrant
-  constexpr int AH = WR * MI * 16, BH = WC * NJ * 16;      // rows per half-tile: 128, 128 | 96
-  constexpr int BNT = 2 * BH;                               // tile width
-  constexpr int UB = BH / 8;                                // 1-KiB DMA units per B half-tile (16 | 12)
-  constexpr bool BSHORT = UB < 16;                          // waves 4-7 stage one unit of a B half-tile, not two
-  constexpr int OFF_A1 = AH * 128, OFF_B0 = 2 * AH * 128, OFF_B1 = OFF_B0 + BH * 128, STAGE = OFF_B1 + BH * 128;
+  constexpr int WR = CFG == 1 ? 4 : 2, WC = 8 / WR;        // wave grid
+  constexpr int MI = CFG == 1 ? 2 : 4, NJ = CFG == 1 ? 3 : 2;  // 16 x 16 MFMA tiles per quadrant (first M half)
+  constexpr int MI1 = CFG == 2 ? 3 : MI;                    // ... of the second M half (CFG 2: 224-row tile)
+  constexpr int AH = WR * MI * 16, AH1 = WR * MI1 * 16, BH = WC * NJ * 16;  // rows per half-tile
+  constexpr int BMT = AH + AH1, BNT = 2 * BH;               // tile height / width
+  constexpr bool BSHORT = BH / 8 < 16;                      // waves 4-7 stage one 1-KiB unit of a B half-tile, not two
+  constexpr bool ASHORT = AH1 / 8 < 16;                     // same for the second A half-tile
+  constexpr int OFF_A1 = AH * 128, OFF_B0 = (AH + AH1) * 128, OFF_B1 = OFF_B0 + BH * 128, STAGE = OFF_B1 + BH * 128;
   constexpr int KSTEP = NSPLIT == 3 ? 32 : 64;
   constexpr bool PAIR = (EPI != VL_EPI_F32);
   constexpr int NJP = PAIR ? (NJ & ~1) : 0;                 // n-tiles [0, NJP) of a quadrant are paired
@@ -406,7 +410,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int tm = swz / p.tiles_n, tn = swz - tm * p.tiles_n;
-  const int row0 = tm * 256, col0 = tn * BNT;
+  const int row0 = tm * BMT, col0 = tn * BNT;
   const int nk = p.K / KSTEP;
 
   // DMA sources: half-tile x in {A0, A1, B0, B1}; unit u = wave + 8*j (8 rows x 128 B); lane -> (row, physical chunk)
@@ -437,14 +441,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   do {                                                                                                           \
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][0] + (long)(kt) * KSTEP),                                \
                                      (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + wave * 1024), 16, 0, 0);  \
-    if (!(BSHORT && (x) >= 2 && late))                                                                           \
+    if (!(late && ((BSHORT && (x) >= 2) || (ASHORT && (x) == 1))))                                               \
       __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][1] + (long)(kt) * KSTEP),                              \
                                        (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + (wave + 8) * 1024), 16, 0, 0); \
   } while (0)
   // wait until everything older than the youngest (nA A-half-tiles + nB B-half-tiles) has landed
 #define G3_WAIT_YOUNGER(nA, nB)                                                                                  \
   do {                                                                                                           \
-    if (BSHORT && late) wait_vmcnt<2 * (nA) + (nB)>();                                                          \
+    if (late) wait_vmcnt<2 * (nA) - ((nA) == 2 && ASHORT ? 1 : 0) + (BSHORT ? 1 : 2) * (nB)>();                  \
     else wait_vmcnt<2 * (nA) + 2 * (nB)>();                                                                      \
   } while (0)
 #define G3_WAIT(issued)                                                                                          \
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     else wait_vmcnt<0>();                                                                                        \
   } while (0)
 
-  f32x4 acc[2][2][MI][NJ];
+  f32x4 acc[2][2][MI][NJ];  // [1][*][i >= MI1] unused
 #pragma unroll
   for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
@@ -465,13 +469,16 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 
   // fragment byte offsets inside a half-tile: [tile][first / second 64-B half of the row], swizzle folded in
   const int frow = lane & 15, fk = lane >> 4;
-  int a_o[MI][2], b_o[NJ][2];
+  constexpr int QA = MI1 == MI ? 1 : 2;  // the row offsets of the two M halves differ only when their heights do
+  int a_o[QA][MI][2], b_o[NJ][2];
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int row = wr * (MI * 16) + i * 16 + frow;
-    a_o[i][0] = row * 128 + ((fk ^ swz3(row)) << 4);
-    a_o[i][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
-  }
+  for (int qa = 0; qa < QA; ++qa)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wr * ((qa == 0 ? MI : MI1) * 16) + i * 16 + frow;
+      a_o[qa][i][0] = row * 128 + ((fk ^ swz3(row)) << 4);
+      a_o[qa][i][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+    }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int row = wc * (NJ * 16) + (j < NJP ? 32 * (j >> 1) + 8 * (frow >> 2) + 4 * (j & 1) + (frow & 3) : j * 16 + frow);
@@ -481,9 +488,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 
   bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
 #define G3_READ_A(st, qm)                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
-    fa[i][0] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[i][0]);                               \
-    fa[i][1] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[i][1]);                               \
+  _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i) {                                          \
+    fa[i][0] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[(qm) % QA][i][0]);                    \
+    fa[i][1] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[(qm) % QA][i][1]);                    \
   }
 #define G3_READ_B(st, qn, fb)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
@@ -500,17 +507,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     __builtin_amdgcn_s_setprio(1);                                                                               \
     if (NSPLIT == 1) {                                                                                           \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                             \
+      _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i)                                         \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
           acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[qm][qn][i][j], 0, 0, 0); \
     } else {                                                                                                     \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                             \
+      _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i)                                         \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
           acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][1], acc[qm][qn][i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                             \
+      _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i)                                         \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
           acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][1], fa[i][0], acc[qm][qn][i][j], 0, 0, 0); \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                             \
+      _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i)                                         \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
           acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][0], acc[qm][qn][i][j], 0, 0, 0); \
     }                                                                                                            \
@@ -568,8 +575,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 #pragma unroll
   for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = row0 + qm * AH + wr * (MI * 16) + i * 16 + (lane & 15);
+    for (int i = 0; i < (qm == 0 ? MI : MI1); ++i) {
+      const int m = row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane & 15);
       if (m >= p.M) continue;
 #pragma unroll
       for (int qn = 0; qn < 2; ++qn)
@@ -865,8 +872,8 @@ int launch2w(GemmArgs a, hipStream_t stream, int splits) {
 }
 template <int NSPLIT, int EPI, int CFG>
 int launch3(GemmArgs a, hipStream_t stream) {
-  constexpr int BNT = CFG == 0 ? 256 : 192;
-  const size_t lds = 2 * (256 + BNT) * 128;
+  constexpr int BMT = CFG == 2 ? 224 : 256, BNT = CFG == 1 ? 192 : 256;
+  const size_t lds = 2 * (BMT + BNT) * 128;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, CFG>),
@@ -874,7 +881,7 @@ int launch3(GemmArgs a, hipStream_t stream) {
     if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  a.tiles_m = (a.M + 255) / 256;
+  a.tiles_m = (a.M + BMT - 1) / BMT;
   a.tiles_n = (a.N + BNT - 1) / BNT;
   hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt(ping-pong)");
@@ -910,12 +917,18 @@ inline bool fast_ok(int64_t M, int64_t K, int64_t k_len, int passes) {
 template <int NSPLIT, int EPI>
 int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
   if (splits == 1 && g_pingpong && (NSPLIT == 1 || g_pp3) && !g_force_generic && a.M >= 256 && a.N >= 192 && (a.K % (NSPLIT == 3 ? 32 : 64)) == 0) {
-    // tile width by "rounds over the 256 CUs x width" (key 7: 1 = automatic, 2 / 3 = force 256 / 192)
+    // tile shape by "rounds over the 256 CUs x tile area" (key 7: 1 = automatic, 2 / 3 / 5 = force 256x256 / 256x192 /
+    // 224x256).  The 224-row tile exists for the two N = 3072 products (FFN1 forward, its dX backward): at
+    // M = 14336 they are 672 tiles = 2.6 rounds of 256x256 but exactly 3 full rounds of 224x256.
     const int64_t tm = (a.M + 255) / 256;
     const int64_t c256 = ((tm * ((a.N + 255) / 256) + 255) / 256) * 256, c192 = ((tm * ((a.N + 191) / 192) + 255) / 256) * 192;
     // 1-pass products are the backward dX GEMMs, which share the chip with the dW GEMMs of the side stream: fewer,
     // wider tiles win there even when they leave CUs to the other stream (A/B in situ: 22.9 vs 23.3 ms / step)
     const bool wide = g_pingpong == 2 || (g_pingpong != 3 && (c256 <= c192 || (NSPLIT == 1 && g_pingpong == 1 && a.N >= 256)));
+    if constexpr ((NSPLIT == 3 && EPI == VL_EPI_GELU_SPLIT) || (NSPLIT == 1 && EPI == VL_EPI_DGELU_BF16)) {
+      const int64_t c224 = (((a.M + 223) / 224) * ((a.N + 255) / 256) + 255) / 256 * 224;
+      if (g_pingpong == 5 || (g_pingpong == 1 && g_tile224 && wide && c224 < c256)) return launch3<NSPLIT, EPI, 2>(a, s);
+    }
     return wide ? launch3<NSPLIT, EPI, 0>(a, s) : launch3<NSPLIT, EPI, 1>(a, s);
   }
   if (fast_ok(a.M, a.K, a.k_len, NSPLIT)) {
@@ -1050,6 +1063,7 @@ extern "C" int vl_debug_set(int key, int value) {
   else if (key == 6) g_ablate = value;
   else if (key == 7) g_pingpong = value;
   else if (key == 8) g_pp3 = value;
+  else if (key == 9) g_tile224 = value;
   else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
   return 0;
 }

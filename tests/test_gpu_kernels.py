@@ -482,3 +482,34 @@ def test_gemm_tn_grouped(K, splits):
             assert torch.equal(p[2], f), it
     with pytest.raises(RuntimeError, match="multiple of 64"):
         ops.gemm_tn_grouped([(probs[0][0][:40], probs[0][1][:40], probs[0][2], None)], 40)
+
+
+@pytest.mark.parametrize("M,N,K", [(448, 512, 256), (300, 260, 192), (1000, 700, 64), (3584, 3072, 768), (2304, 520, 96)])
+def test_gemm_224_row_tiles(M, N, K):
+    """The 224 x 256 ping-pong tile (FFN1 forward / its dX backward at B*S = 14336: 3 full rounds instead of 2.6) computes
+    the same sums in the same order as the 256 x 256 tile: bit-identical outputs for both fused epilogues."""
+    from clg_vqa_amd import _lib
+    L = _lib.lib()
+    x, w, bias = _rand(M, K, seed=70), _rand(N, K, seed=71, scale=0.1), _rand(N, seed=72)
+    xh, xl = _split(x)
+    wh, wl = _split(w)
+    outs = {}
+    try:
+        for width in (2, 5):
+            L.vl_debug_set(7, width)
+            u16 = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
+            hh, hl, dh = torch.full_like(u16, float("nan")), torch.full_like(u16, float("nan")), torch.full_like(u16, float("nan"))
+            if K % 32 == 0:
+                ops.gemm_nt(xh, xl, wh, wl, M, N, K, 3, EPI_GELU_SPLIT, bias=bias, out_hi=hh, out_lo=hl, aux16=u16)
+            if K % 64 == 0:
+                aux = _rand(M, N, seed=73).to(BF16)
+                ops.gemm_nt(xh, None, wh, None, M, N, K, 1, EPI_DGELU_BF16, out_hi=dh, aux16=aux)
+            outs[width] = (u16, hh, hl, dh)
+    finally:
+        L.vl_debug_set(7, 1)
+    for a, b in zip(outs[2], outs[5]):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))  # bit patterns (NaN-filled where not computed)
+    if K % 32 == 0:
+        u_ref = (x.double() @ w.double().t() + bias.double()).float()
+        torch.testing.assert_close(outs[5][0].float(), u_ref, rtol=2 ** -8, atol=1e-4)
+        torch.testing.assert_close(outs[5][1].float() + outs[5][2].float(), _gelu(u_ref), rtol=1e-4, atol=1e-4)
