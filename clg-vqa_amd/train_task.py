@@ -23,6 +23,7 @@ import torch.distributed as dist
 
 from . import sft, task_utils, train_utils
 from .config import BertConfig, load_task_cfg
+from .data import DevicePrefetcher
 from .encoders import BertForVLTasks
 from .optim import FusedAdamW
 from .synthetic import make_batch
@@ -158,8 +159,10 @@ def main(argv=None):
     step_id = 0
     for epoch in range(start_epoch, num_epoch):
         t0, seen = time.time(), 0
-        for it in range(args.steps_per_epoch):
-            batch = _batch(args, task_cfg, task, config, step_id, rank, bs)
+        # batches are staged to HBM two steps ahead on a copy stream (the reference copies inside the step)
+        first = step_id
+        host_batches = (_batch(args, task_cfg, task, config, first + i, rank, bs) for i in range(args.steps_per_epoch))
+        for it, batch in enumerate(DevicePrefetcher(host_batches, device, depth=2)):
             step_id += 1
             loss, score = task_utils.ForwardModelsTrain(config, task_cfg, device, task, batch, model, criterion)
             if args.grad_acc_steps > 1:

@@ -78,3 +78,17 @@ def test_two_ranks_reduce_to_the_gradient_of_the_concatenated_batch():
     scale = ref.abs().max().item()
     err = (got[0]["grad"] - ref).abs().max().item()
     assert err <= 2e-3 * scale, (err, scale)  # backward GEMMs round their operands to bf16 per batch composition
+
+
+def test_device_prefetcher_stages_batches_in_order_and_unchanged():
+    from clg_vqa_amd.data import DevicePrefetcher
+    from clg_vqa_amd.synthetic import make_batch
+    batches = [make_batch(3, vocab_size=999, seed=s) for s in range(7)]
+    got = list(DevicePrefetcher(iter(batches), "cuda", depth=2))
+    assert len(got) == len(batches)
+    for ref, dev in zip(batches, got):
+        assert len(ref) == len(dev)
+        for a, b in zip(ref, dev):
+            assert b.is_cuda and b.dtype == a.dtype and torch.equal(b.cpu(), a)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        DevicePrefetcher(iter(batches), "cpu")
