@@ -84,7 +84,10 @@ def test_wide_layer_matches_reference_fixture():
     print("wide fixture: worst gradient rel-L2 error %.3e at %s" % worst)
 
 
-@pytest.mark.parametrize("n_layers,B,T,V", [(2, 8, 20, 36), (3, 4, 40, 36), (2, 2, 20, 100)])
+@pytest.mark.parametrize("n_layers,B,T,V", [(2, 8, 20, 36), (3, 4, 40, 36), (2, 2, 20, 100),
+                                            (2, 1, 6, 4),      # one sample, 10 rows in all: every tile is ragged
+                                            (1, 3, 7, 9),      # odd everything (S = 16)
+                                            (1, 2, 60, 100)])  # the longest stream the attention kernel takes (S = 160)
 def test_multi_layer_against_oracle(n_layers, B, T, V):
     config = BertConfig.from_dict(uc2_cfg_dict(n_layers=n_layers, vocab=2000))
     model, oracle = _build(config, seed=11 + n_layers)
@@ -154,6 +157,18 @@ def test_training_mode_dropout_runs_and_is_seeded():
     model.eval()
     le, _, _ = _run_native(model, batch, train_mode=False)
     assert abs(float(l1) - float(le)) > 1e-6  # dropout really was active
+
+
+def test_unsupported_shapes_are_rejected_loudly():
+    config = BertConfig.from_dict(uc2_cfg_dict(n_layers=1, vocab=100))
+    model = BertForVLTasks(config, TASK_CFG, ["TASK15"]).cuda()
+    b = tuple(t.cuda() for t in make_batch(1, seq_len=61, num_boxes=100, vocab_size=100))  # S = 161 > 160
+    with pytest.raises(RuntimeError, match="160|S"):
+        model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])
+    bad = uc2_cfg_dict(n_layers=1, vocab=100)
+    bad["tv_attn_sublayers"] = []  # not the UC2 topology
+    with pytest.raises(ValueError, match="UC2 single-stream topology"):
+        BertForVLTasks(BertConfig.from_dict(bad), TASK_CFG, ["TASK15"])
 
 
 def test_cpu_tensors_are_rejected_loudly():
