@@ -183,6 +183,8 @@ def main():
     for kv in filter(None, os.environ.get("VL_DEBUG", "").split(",")):  # tuning knobs, e.g. VL_DEBUG=7:0,8:1
         k, v = kv.split(":")
         _lib.lib().vl_debug_set(int(k), int(v))
+    if os.environ.get("VL_LN_BLOCKS"):
+        _lib.lib().vl_ln_debug_blocks(int(os.environ["VL_LN_BLOCKS"]))
     num_boxes, num_locs, l2n = 36, 7, False
     if args.workload in ("c3", "c5"):
         args.sft = True

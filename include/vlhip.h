@@ -121,6 +121,7 @@ int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, int64_t
  * GEMM); column sums over the M rows: dgamma, dbeta, dbias (= colsum(dL/dy), the producing dense layer's bias
  * gradient; may be NULL).  partial_ws: >= vl_ln_bwd_ws_floats(M, H) floats of scratch. */
 int64_t vl_ln_bwd_ws_floats(int64_t M, int64_t H);
+int vl_ln_debug_blocks(int n); /* A/B knob: workgroups (= partial row-sets) of vl_ln_bwd; call before sizing the workspace */
 int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd, const float* gamma,
               const float* row_pre, const float* row_post, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta, float* dbias,
               float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
