@@ -64,7 +64,10 @@ class GemmTimer(object):
             e0.record()
             inner(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw)
             e1.record()
-            timer.records.append((passes, 2.0 * M * N * K, e0, e1))
+            opb = 2 * (2 if passes == 3 else 1)  # bytes per operand element: bf16 hi (+ lo)
+            nbytes = opb * (M * K + N * K) + sum((4 if k in ("resid", "out32") else 2) * M * N
+                                                 for k in ("resid", "out32", "out_hi", "out_lo", "aux16") if kw.get(k) is not None)
+            timer.records.append((passes, 2.0 * M * N * K, e0, e1, nbytes))
 
         ops_mod.gemm_nt = gemm_nt
 
@@ -74,7 +77,8 @@ class GemmTimer(object):
             recs = [r for r in self.records if r[0] == passes]
             if recs:
                 ms = sum(r[2].elapsed_time(r[3]) for r in recs)
-                out[passes] = dict(launches=len(recs), flops=sum(r[1] for r in recs), ms=ms)
+                out[passes] = dict(launches=len(recs), flops=sum(r[1] for r in recs), ms=ms,
+                                   bytes_per_launch=sum(r[4] for r in recs) / len(recs))
         return out
 
 
@@ -152,6 +156,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs[1..4]: c2 UC2 dense (the headline), c3 = c2 + SFT masks, c4 M3P with 100 "
                          "boxes, c5 UC2 with 100 boxes + SFT at bs 128")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measurements outside the timed region "
+                    "(forward+backward only, PCIe-inclusive, reference batch semantics): used under the profiler")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank logic on a single GPU)")
     args = ap.parse_args()
@@ -214,6 +220,8 @@ def main():
             mask = (torch.rand(w.shape, generator=gen) < 0.59).float().to(dev)
             w.data.mul_(mask)
             prune.CustomFromMask.apply(mods[n], "weight", mask=mask)
+    if os.environ.get("BENCH_EARLY_JOIN", "0") == "1":
+        model.engine.stack.early_join = True
     if os.environ.get("BENCH_GROUP_DW", "0") == "1":  # A/B: one grouped weight-gradient launch per layer
         model.engine.stack.group_dw = True
     model.train()
@@ -281,15 +289,17 @@ def main():
     def fwd_bwd():
         loss_, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, dev, "TASK15", batch, model, crit)
         loss_.backward()
-    n_extra = max(3, args.steps // 2)
-    opt.set_overlap(False)  # no optimizer step between these backward passes
-    fwd_bwd()
-    fb_rate = world * args.batch * n_extra / timed(fwd_bwd, n_extra)
-    opt.zero_grad()
-    opt.set_overlap(True)
+    n_extra = 0 if args.no_extras else max(3, args.steps // 2)
+    fb_rate = None
+    if n_extra:
+        opt.set_overlap(False)  # no optimizer step between these backward passes
+        fwd_bwd()
+        fb_rate = world * args.batch * n_extra / timed(fwd_bwd, n_extra)
+        opt.zero_grad()
+        opt.set_overlap(True)
     # (iii) PCIe-inclusive: every step's batch comes from pinned host memory through the copy-stream prefetcher
     h2d_rate = None
-    if world == 1:
+    if world == 1 and n_extra:
         from clg_vqa_amd.data import DevicePrefetcher
         pinned = [tuple(t.pin_memory() for t in make_batch(args.batch, num_boxes=num_boxes, num_locs=num_locs, l2_normalize=l2n,
                                                          seed=77 + i)) for i in range(3)]
@@ -303,7 +313,7 @@ def main():
         fed_step()
         h2d_rate = args.batch * n_extra / timed(fed_step, n_extra)
     strong_rate = None
-    if world > 1 and args.workload in ("c2", "c3"):
+    if world > 1 and n_extra and args.workload in ("c2", "c3"):
         small = tuple(t.to(dev) for t in make_batch(max(1, 256 // world), num_boxes=num_boxes, num_locs=num_locs,
                                                     l2_normalize=l2n, seed=4321 + rank))
 
@@ -325,7 +335,7 @@ def main():
             ach = gs[3]["flops"] / (gs[3]["ms"] * 1e-3) / 1e12
             roof = dict(bound="mfma", kernel="gemm3_kernel<3,*> (forward GEMMs, 3-pass split bf16 MFMA, 8-wave ping-pong)", achieved=round(ach, 2),
                         peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                        traffic=pmc_traffic_per_launch(), algorithmic_bytes_per_launch=None, mfma_passes=3, mfma_issue_frac=round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        traffic=pmc_traffic_per_launch(), algorithmic_bytes_per_launch=round(gs[3]["bytes_per_launch"]), mfma_passes=3, mfma_issue_frac=round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
                         launches=gs[3]["launches"], avg_launch_us=round(1e3 * gs[3]["ms"] / gs[3]["launches"], 2))
             if 1 in gs:
                 a1 = gs[1]["flops"] / (gs[1]["ms"] * 1e-3) / 1e12
@@ -351,7 +361,7 @@ def main():
         }
         gflop_per_sample = {"c2": 29.241, "c3": 29.241, "c4": 63.72, "c5": 63.71}[args.workload]
         line["step_tflops"] = round(gflop_per_sample * 1e-3 * world * args.batch / (elapsed / args.steps), 2)
-        line["extras"] = {"fwd_bwd_only_samples_per_s": round(fb_rate, 1),
+        line["extras"] = {"fwd_bwd_only_samples_per_s": None if fb_rate is None else round(fb_rate, 1),
                           "h2d_inclusive_samples_per_s": None if h2d_rate is None else round(h2d_rate, 1),
                           "reference_semantics_global256_samples_per_s": None if strong_rate is None else round(strong_rate, 1)}
         print("[bench] gpu part done: %.1f samples/s, %.2f ms/step" % (value, 1e3 * elapsed / args.steps), file=sys.stderr, flush=True)

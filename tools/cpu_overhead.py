@@ -62,6 +62,7 @@ def direct():
             eng.backward(sv, torch.ones_like(out))
     finally:
         ops.set_stream(None)
+        eng.stack.join()
 
 
 for _ in range(3):

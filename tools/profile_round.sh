@@ -6,12 +6,12 @@ R=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$R
 rm -rf $OUT && mkdir -p $OUT
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -3 $OUT/stats.log; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1 || { echo "stats pass failed"; tail -3 $OUT/stats.log; exit 1; }
 echo "stats done"
 i=0
 for ctr in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAVE_CYCLES"; do
   i=$((i+1))
-  timeout -k 10 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i ($ctr) failed"; grep -m3 -i "error\|fail" $OUT/pmc$i.log; exit 1; }
+  timeout -k 10 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i ($ctr) failed"; grep -m3 -i "error\|fail" $OUT/pmc$i.log; exit 1; }
   echo "pmc$i ($ctr) done"
 done
 python3 tools/profile_summary.py --round $R --stats $OUT/stats --steps 4 --pmc $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 --out $OUT/summary
