@@ -196,7 +196,10 @@ class FusedAdamW(object):
         self._pre, self._works, self._layer_plan = set(), [], None
         self.keep_reduced_grad = False
         if overlap_reduce is None:
-            overlap_reduce = self.reducer.world_size() > 1
+            # also with one GPU: the layer gradients then reach the arena by one multi-tensor copy per layer on the
+            # weight-gradient stream instead of ~90 autograd copies (views of the packed Q/K/V gradient) + one big
+            # gather on the main stream (-0.4 ms per step); further backward passes before step() accumulate
+            overlap_reduce = True
         if overlap_reduce and eng is not None and hasattr(eng, "stack"):
             index_of = {id(g[1]): i for i, g in enumerate(self.groups)}
             plan = []
@@ -233,11 +236,16 @@ class FusedAdamW(object):
         if plan is None:
             return False
         idx, views, ranges = plan
-        if self._pre.intersection(idx):
+        again = bool(self._pre.intersection(idx))
+        if again and self.reducer.world_size() > 1:
             raise RuntimeError("clg_vqa_amd.FusedAdamW: a second backward arrived before step(); construct the optimizer "
                                "with overlap_reduce=False when accumulating gradients over micro-batches")
         with torch.cuda.stream(stream):  # behind this layer's weight-gradient kernels
-            torch._foreach_copy_(views, [g.view_as(v) for g, v in zip(grads, views)])
+            src = [g.view_as(v) for g, v in zip(grads, views)]
+            if again:  # one GPU, gradient accumulation: add to what the earlier backward left in the arena
+                torch._foreach_add_(views, src)
+            else:
+                torch._foreach_copy_(views, src)
             if self.reducer.world_size() > 1:
                 self._works += self.reducer.allreduce_async(self.arena.grad, ranges)
         self._pre.update(idx)
