@@ -53,6 +53,10 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* src, long ld
 //  * K/V rows are padded to 65 floats: the permuted operand reads (row = lane&15, col = 16*k4 + step) hit 32
 //    distinct banks.
 constexpr int LDK = 65;
+// V rows are padded to 80 floats: the P.V operand read (row = 4*step + k4, col = 16*dt + lane&15) then spreads the two
+// k4 values of a 32-lane half over banks 0-15 / 16-31 (with 65 they overlapped: 2-way conflicts on every read); 16-byte
+// aligned rows also let V be staged with one ds_write_b128 per float4.
+constexpr int LDV = 80;
 
 __device__ __forceinline__ void store_row4(float* dst, const float4& v) {  // rows are only 4-byte aligned (LDK odd)
   dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
@@ -65,8 +69,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
   constexpr bool SHARE = NT <= 4;        // single trip: K and V share one buffer
   constexpr int NLD = (Spad * 16 + 255) / 256;  // float4 loads per thread to stage one [Spad][64] matrix
   float* sK = smf;
-  float* sV = SHARE ? sK : sK + Spad * LDK;
-  float* smask = sV + Spad * LDK;
+  float* sV = SHARE ? sK : sK + Spad * LDK;  // Spad * 65 floats is a multiple of 16 bytes: V rows stay 16-byte aligned
+  float* smask = sV + Spad * LDV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* sP = smask + Spad + wave * (16 * LDP);
 
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     const int idx = tid + t * 256, row = idx >> 4, c4 = idx & 15;
     if (idx < Spad * 16) {
       store_row4(sK + row * LDK + c4 * 4, rk[t]);
-      if (!SHARE) store_row4(sV + row * LDK + c4 * 4, rv[t]);
+      if (!SHARE) *reinterpret_cast<float4*>(sV + row * LDV + c4 * 4) = rv[t];
     }
   }
 
@@ -168,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
       for (int t = 0; t < NLD; ++t) {
         const int idx = tid + t * 256, row = idx >> 4, c4 = idx & 15;
-        if (idx < Spad * 16) store_row4(sV + row * LDK + c4 * 4, rv[t]);
+        if (idx < Spad * 16) *reinterpret_cast<float4*>(sV + row * LDV + c4 * 4) = rv[t];
       }
       __syncthreads();
     }
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
       for (int ks = 0; ks < Spad / 4; ++ks) {
         const float a = sP[i16 * LDP + 4 * ks + k4];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma4(a, sV[(4 * ks + k4) * LDK + dt * 16 + i16], o[dt]);
+        for (int dt = 0; dt < 4; ++dt) o[dt] = mfma4(a, sV[(4 * ks + k4) * LDV + dt * 16 + i16], o[dt]);
       }
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
 
 inline size_t fwd_lds_bytes(int NT) {
   const int Spad = NT * 16, LDP = Spad + 2;
-  return sizeof(float) * (size_t)((NT <= 4 ? 1 : 2) * Spad * 65 + Spad + 4 * 16 * LDP);
+  return sizeof(float) * (size_t)((NT <= 4 ? 0 : Spad * LDK) + Spad * LDV + Spad + 4 * 16 * LDP);
 }
 inline size_t bwd_lds_bytes(int NT) {
   const int Spad = NT * 16, LDP = Spad + 2;
