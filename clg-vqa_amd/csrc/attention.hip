@@ -310,12 +310,16 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnArgs p) {
       if (kt < NT) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {  // 16 queries = 4 k-steps
-          const float apd = sPd[(4 * ks + k4) * LDP + kt * 16 + i16];
-          const float ads = sdS[(4 * ks + k4) * LDP + kt * 16 + i16];
+          // which 4 queries form a step is free as long as both operands agree: lane group k4 takes query
+          // ks + {0, 8, 4, 12}[k4], so the two groups of a 32-lane half read rows 8 apart = 16 banks apart (rows are
+          // 66 floats) and the row reads below are conflict-free (4*ks + k4 put them 2 banks apart: 2-way conflicts)
+          const int kq = ks + 8 * (k4 & 1) + 4 * (k4 >> 1);
+          const float apd = sPd[kq * LDP + kt * 16 + i16];
+          const float ads = sdS[kq * LDP + kt * 16 + i16];
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            dV[i][dt] = mfma4(apd, sdO[(4 * ks + k4) * LDT + dt * 16 + i16], dV[i][dt]);
-            dK[i][dt] = mfma4(ads, sQ[(4 * ks + k4) * LDT + dt * 16 + i16], dK[i][dt]);
+            dV[i][dt] = mfma4(apd, sdO[kq * LDT + dt * 16 + i16], dV[i][dt]);
+            dK[i][dt] = mfma4(ads, sQ[kq * LDT + dt * 16 + i16], dK[i][dt]);
           }
         }
       }
