@@ -116,23 +116,39 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_raw* __restri
 // ---- column sums of a bf16 matrix (bias gradients) ------------------------------------------------------------
 constexpr int CS_ROWBLOCKS = 128;
 __global__ __launch_bounds__(256) void colsum_stage1(const bf16_raw* __restrict__ x, int M, int N, long ld,
-                                                     float* __restrict__ ws) {
-  __shared__ float4 red[4][64];
-  const int cg = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int n = (blockIdx.x * 64 + cg) * 4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                                                     float* __restrict__ ws, int vec8) {
+  // 256 columns per workgroup: 32 column groups of 8 (one 16-byte load per row) x 8 row lanes
+  __shared__ float red[8][256 + 8];
+  const int cg = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int n = blockIdx.x * 256 + cg * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (n < N) {
-    for (int m = blockIdx.y * 4 + ty; m < M; m += gridDim.y * 4) {
-      const ushort4 v = *reinterpret_cast<const ushort4*>(x + (long)m * ld + n);
-      acc.x += bf16_to_f32(v.x); acc.y += bf16_to_f32(v.y); acc.z += bf16_to_f32(v.z); acc.w += bf16_to_f32(v.w);
+    if (vec8 && n + 7 < N) {
+      for (int m = blockIdx.y * 8 + ty; m < M; m += gridDim.y * 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (long)m * ld + n);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          acc[2 * t] += __uint_as_float(w[t] << 16);
+          acc[2 * t + 1] += __uint_as_float(w[t] & 0xFFFF0000u);
+        }
+      }
+    } else {
+      for (int m = blockIdx.y * 8 + ty; m < M; m += gridDim.y * 8)
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          if (n + t < N) acc[t] += bf16_to_f32(x[(long)m * ld + n + t]);
     }
   }
-  red[ty][cg] = acc;
+#pragma unroll
+  for (int t = 0; t < 8; ++t) red[ty][cg * 8 + t] = acc[t];
   __syncthreads();
-  if (ty == 0 && n < N) {
-    float4 s = red[0][cg];
-    for (int t = 1; t < 4; ++t) { s.x += red[t][cg].x; s.y += red[t][cg].y; s.z += red[t][cg].z; s.w += red[t][cg].w; }
-    *reinterpret_cast<float4*>(ws + (long)blockIdx.y * N + n) = s;
+  const int c = threadIdx.x;  // one column per thread
+  if (blockIdx.x * 256 + c < N) {
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s2 += red[t][c];
+    ws[(long)blockIdx.y * N + blockIdx.x * 256 + c] = s2;
   }
 }
 __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ ws, int nrb, int N,
@@ -413,7 +429,7 @@ extern "C" int vl_transpose_bf16(const void* in, void* out, int64_t M, int64_t N
 }
 
 extern "C" int64_t vl_colsum_ws_floats(int64_t M, int64_t N) {
-  int64_t rb = (M + 3) / 4;
+  int64_t rb = (M + 7) / 8;
   if (rb > CS_ROWBLOCKS) rb = CS_ROWBLOCKS;
   return rb * N;
 }
@@ -421,10 +437,11 @@ extern "C" int vl_colsum_bf16(const void* x16, int64_t M, int64_t N, int64_t ld,
                               void* stream) {
   VL_CHECK_ARG(x16 && ws && out32 && M > 0 && N > 0, "vl_colsum_bf16: bad arguments");
   VL_CHECK_ARG(N % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x16 & 7) == 0, "vl_colsum_bf16: N, ld must be multiples of 4");
-  int64_t rb = (M + 3) / 4;
+  int64_t rb = (M + 7) / 8;
   if (rb > CS_ROWBLOCKS) rb = CS_ROWBLOCKS;
+  const int vec8 = (ld % 8 == 0) && (((uintptr_t)x16 & 15) == 0);
   hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)((N + 255) / 256), (unsigned)rb), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_raw*)x16, (int)M, (int)N, (long)ld, ws);
+                     (hipStream_t)stream, (const bf16_raw*)x16, (int)M, (int)N, (long)ld, ws, vec8);
   VL_CHECK_LAUNCH("vl_colsum_bf16");
   hipLaunchKernelGGL(colsum_stage2, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, ws, (int)rb,
                      (int)N, out32);

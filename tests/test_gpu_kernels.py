@@ -359,6 +359,12 @@ def test_mask_mul_weight_prep_transpose_colsum():
     cs = torch.empty(72, device=DEV)
     ops.colsum_bf16(x, 300, 72, cs)
     torch.testing.assert_close(cs, x.float().sum(0), rtol=1e-5, atol=1e-4)
+    for M, N, off in [(14336, 3072, 0), (1000, 2304, 0), (77, 20, 0), (513, 768, 768)]:  # 16-byte path, ragged, column slice
+        wide = _rand(M, N + off + 8, seed=29).to(BF16)
+        xs = wide[:, off:off + N]
+        cs = torch.full((N,), float("nan"), device=DEV)
+        ops.colsum_bf16(xs, M, N, cs)
+        torch.testing.assert_close(cs, xs.double().sum(0).float(), rtol=1e-5, atol=1e-3 * math.sqrt(M / 256))
 
 
 def test_addmask_embeddings_loc():
