@@ -233,6 +233,7 @@ template <int NV>
 int launch_bwd(const LnArgs& a, hipStream_t s, float* dgamma, float* dbeta, float* dbias) {
   hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(a.nblk), dim3(256), 0, s, a);
   VL_CHECK_LAUNCH("vl_ln_bwd");
+  if (!dgamma && !dbeta && !dbias) return 0;  // partials only: the caller sums them with vl_ln_bwd_reduce
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * a.H + 15) / 16), dim3(256), 0, s, a.ws, a.nblk, a.H,
                      dgamma, dbeta, dbias);
   VL_CHECK_LAUNCH("vl_ln_bwd(reduce)");
@@ -299,4 +300,17 @@ extern "C" int vl_ln_bwd(const float* dy32, const float* z32, const float* mean,
     case 6: return launch_bwd<6>(a, s, dgamma, dbeta, dbias);
     default: return launch_bwd<8>(a, s, dgamma, dbeta, dbias);
   }
+}
+
+// Second half of vl_ln_bwd on its own (any stream that is ordered after the vl_ln_bwd call which filled partial_ws with
+// dgamma = dbeta = dbias = NULL): the column sums are only needed by the optimizer, so the training engine runs this
+// 15-us launch on the weight-gradient stream instead of between the kernels of the backward critical path.
+extern "C" int vl_ln_bwd_reduce(const float* partial_ws, int64_t M, int64_t H, float* dgamma, float* dbeta,
+                                float* dbias, void* stream) {
+  if (int rc = check_shape("vl_ln_bwd_reduce", M, H, 1, 0.f, 0.f)) return rc;
+  VL_CHECK_ARG(partial_ws, "vl_ln_bwd_reduce: null workspace");
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((3 * H + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                     partial_ws, nblk_for(M), (int)H, dgamma, dbeta, dbias);
+  VL_CHECK_LAUNCH("vl_ln_bwd_reduce");
+  return 0;
 }

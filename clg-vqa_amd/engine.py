@@ -147,6 +147,7 @@ class LayerStack(object):
         # second HIP stream so that their workgroups fill the CUs the dX / LayerNorm / attention kernels leave idle
         self.overlap_dw = True
         self._pending = None
+        self.side_reduce = False  # LayerNorm-backward column sums on the weight-gradient stream: measured +0.1 ms (that stream is the longer one)
         self.early_join = False  # A/B knob: join the streams at the end of the layer stack instead of the trunk
         self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
         self._fork = None
@@ -203,6 +204,7 @@ class LayerStack(object):
         keep = []  # operands of side-stream kernels stay referenced until the streams are joined
         # one grouped weight-gradient launch per layer needs B*S % 64 == 0 and 8-aligned feature sizes
         grouped = self.group_dw and M % 64 == 0 and H % 8 == 0 and I % 8 == 0
+        defer_red = side is not None and self.side_reduce
 
         main_ptr = main.cuda_stream
         side_ptr = side.cuda_stream if side is not None else None
@@ -229,8 +231,17 @@ class LayerStack(object):
             sp, lw, ls = self.specs[l], pw_layers[l], saved[l]
             dz2, dt2 = f32(M, H), b16(M, H)
             dg2, db2, dbias2 = f32(H), f32(H), f32(H)
-            ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, dg2, db2, dbias2,
-                       ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
+            # the column sums (dgamma, dbeta, the dense layer's bias gradient) are only needed by the optimizer: the
+            # main stream leaves per-workgroup partials (own workspace per call) and the 15-us reduce launch goes to
+            # the weight-gradient stream instead of sitting between the kernels of the critical path
+            ws2 = ops.ln_bwd_ws(M, H, dev) if defer_red else ws
+            if defer_red:
+                ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, None, None,
+                           None, ws2, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
+                on_side(lambda: ops.ln_bwd_reduce(ws2, M, H, dg2, db2, dbias2), ws2)
+            else:
+                ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, dg2, db2,
+                           dbias2, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
             du16 = b16(M, I)
             ops.gemm_nt(dt2, None, lw["w2"].t_hi, None, M, I, H, 1, EPI_DGELU_BF16, out_hi=du16, aux16=ls["u16"])
             if not grouped:
@@ -242,8 +253,14 @@ class LayerStack(object):
             ops.gemm_nt(du16, None, lw["w1"].t_hi, None, M, H, I, 1, EPI_F32, resid=dz2, out32=dx1)
             dz1, dt1 = f32(M, H), b16(M, H)
             dg1, db1, dbias_o = f32(H), f32(H), f32(H)
-            ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, dg1, db1,
-                       dbias_o, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
+            ws1 = ops.ln_bwd_ws(M, H, dev) if defer_red else ws
+            if defer_red:
+                ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, None, None,
+                           None, ws1, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
+                on_side(lambda: ops.ln_bwd_reduce(ws1, M, H, dg1, db1, dbias_o), ws1)
+            else:
+                ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, dg1, db1,
+                           dbias_o, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
             if not grouped:
                 dWo = on_side(lambda: _masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), sp.o), dt1, ls["ctx_hi"])
             dctx = f32(M, H)

@@ -162,6 +162,11 @@ def ln_bwd(dy, z, mean, rstd, gamma, dz, dpre16, dpre32, dgamma, dbeta, dbias, w
                                     float(p_pre), float(p_post), int(seed), _stream()), "vl_ln_bwd")
 
 
+def ln_bwd_reduce(ws, M, H, dgamma, dbeta, dbias):
+    """Column sums of the partials a ln_bwd(..., dgamma=None, dbeta=None, dbias=None) call left in ws."""
+    _lib.check(_lib.lib().vl_ln_bwd_reduce(_p(ws), M, H, _p(dgamma), _p(dbeta), _p(dbias), _stream()), "vl_ln_bwd_reduce")
+
+
 def mask_mul(a, m, out):
     """out = a (*) m : SFT weight_orig * weight_mask and grad (*) mask."""
     assert a.numel() == m.numel() == out.numel()

@@ -126,6 +126,10 @@ int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const floa
               const float* row_pre, const float* row_post, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta, float* dbias,
               float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
               float p_pre, float p_post, uint64_t seed, void* stream);
+/* dgamma = dbeta = dbias = NULL makes vl_ln_bwd stop after the per-workgroup partials; this sums them later, on any
+ * stream ordered after that call (the engine uses the weight-gradient stream: off the backward critical path). */
+int vl_ln_bwd_reduce(const float* partial_ws, int64_t M, int64_t H, float* dgamma, float* dbeta, float* dbias,
+                     void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Sparse fine-tuning mask kernels.

@@ -324,6 +324,13 @@ def test_layernorm_row_map_and_dropout():
     ops.ln_bwd(dy, z2, mean, rstd, gamma, dz, None, dpre, dg, db, dbias, ops.ln_bwd_ws(B * V, H, DEV), B * V, H,
                p_pre=p, seed=5)
     assert torch.equal(dpre != 0, kept & (dz != 0))
+    # the two halves of the backward on their own: partials only, then the column sums -- identical to the fused call
+    ws2 = ops.ln_bwd_ws(B * V, H, DEV)
+    dz_b, dpre_b = torch.empty_like(y), torch.empty_like(y)
+    ops.ln_bwd(dy, z2, mean, rstd, gamma, dz_b, None, dpre_b, None, None, None, ws2, B * V, H, p_pre=p, seed=5)
+    dg_b, db_b, dbias_b = torch.empty(H, device=DEV), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    ops.ln_bwd_reduce(ws2, B * V, H, dg_b, db_b, dbias_b)
+    assert torch.equal(dz_b, dz) and torch.equal(dg_b, dg) and torch.equal(db_b, db) and torch.equal(dbias_b, dbias)
     torch.testing.assert_close(dpre[kept], (dz / (1 - p))[kept], rtol=1e-6, atol=1e-7)
     z3 = y.clone()
     out3 = torch.empty(B * V, H, device=DEV)
