@@ -32,12 +32,9 @@ namespace {
 
 int g_force_bn = 0;       // tuning knobs (vl_debug_set): 0 = automatic
 int g_force_generic = 0;
-int g_wave_rows = 4;      // 2: 512-thread workgroups (8 waves), 4: 1024-thread workgroups (16 waves)
-int g_alias_rows = 0;
 int g_pingpong = 1;   // 8-wave ping-pong kernel (key 7): 0 = off, 1 = automatic tile width, 2 / 3 = force 256 / 192, 4 = cost model only
 int g_pp3 = 1;        // key 8: 3-pass products on the ping-pong kernel too
 int g_tile224 = 1;    // key 9: allow the 224 x 256 tile
-int g_ablate = 0;     // timing experiment only: A rows wrap modulo this (makes the A operand cache resident)
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -49,8 +46,6 @@ struct GemmArgs {
   const float* bias; const float* resid; float* out32; long ldc;
   bf16_raw* out_hi; bf16_raw* out_lo; bf16_raw* aux16; long ld16;
   int tiles_m, tiles_n;
-  int alias_rows;               // debug / timing experiment (0 = off)
-  int ablate;                   // timing experiment only (wrong results): 1 = no DMA inside the K loop
   int vec8;                     // 1: additionally 16-byte bf16 epilogue accesses are legal (ld16 % 8 == 0, 16-B pointers)
   int vec;                      // 1: leading dimensions / pointers allow the 16-byte (fp32) / 8-byte (bf16) epilogue
   int splits;                   // TN kernel: number of K-ranges (1-D grid over splits x tiles)
@@ -242,7 +237,6 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
     int grow = (isB ? col0 : row0) + trow;
     const int lim = (isB ? p.N : p.M) - 1;
     grow = grow < lim ? grow : lim;  // rows past the edge re-read the last row; their products are never stored
-    if (!isB && p.alias_rows) grow %= p.alias_rows;
     const int fsw = (PAIR && isB) ? (((0x78 >> (2 * ((trow >> 3) & 3))) & 3) | (((trow >> 1) & 1) << 2))
                                   : ((trow >> 1) & 7);
     const int lc = (lane & 7) ^ fsw;  // logical 16-B chunk that lands at physical position lane&7
@@ -291,7 +285,7 @@ __global__ __launch_bounds__(WM * 256, WM) void gemm2_kernel(GemmArgs p) {
   __syncthreads();  // waits vmcnt(0) for the DMA, then the workgroup barrier
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
-    if (kt + 1 < nk && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
     if (NSPLIT == 1) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -863,8 +857,6 @@ int launch2w(GemmArgs a, hipStream_t stream, int splits) {
   }
   a.tiles_m = (a.M + 255) / 256;
   a.tiles_n = (a.N + BN - 1) / BN;
-  a.alias_rows = g_alias_rows;
-  a.ablate = g_ablate;
   hipLaunchKernelGGL((gemm2_kernel<NSPLIT, EPI, BN, WM>), dim3(a.tiles_m * a.tiles_n, splits), dim3(WM * 256), lds,
                      stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt(fast)");
@@ -1053,14 +1045,12 @@ extern "C" int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi
   return 0;
 }
 
-// Tuning / A-B knobs for benchmarking (not part of the drop-in surface): key 1 = force BN of the fast GEMM path
-// (0 = auto), key 2 = force the generic 128x128 kernel.
+// A/B knobs for benchmarking (not part of the drop-in surface): 1 = BN of the single-barrier kernel (0 = auto),
+// 2 = force the generic 128x128 kernel, 7 = ping-pong kernel (0 off, 1 auto, 2 / 3 / 5 = force 256x256 / 256x192 /
+// 224x256 tiles, 4 = cost model only), 8 = ping-pong for 3-pass products, 9 = allow the 224x256 tile.
 extern "C" int vl_debug_set(int key, int value) {
   if (key == 1) g_force_bn = value;
   else if (key == 2) g_force_generic = value;
-  else if (key == 3) g_alias_rows = value;
-  else if (key == 4) g_wave_rows = value;
-  else if (key == 6) g_ablate = value;
   else if (key == 7) g_pingpong = value;
   else if (key == 8) g_pp3 = value;
   else if (key == 9) g_tile224 = value;

@@ -49,9 +49,6 @@ def main():
             for vname, v in variants:
                 L.vl_debug_set(2, v["g"])
                 L.vl_debug_set(1, v["bn"])
-                L.vl_debug_set(3, v.get("alias", 0))
-                L.vl_debug_set(4, v.get("wr", 2))
-                L.vl_debug_set(6, v.get("ab", 0))
                 L.vl_debug_set(7, v.get("pp", 0))
                 def run():
                     it[0] += 1
@@ -69,9 +66,6 @@ def main():
             print("%s M=%5d N=%4d K=%4d | %s" % (name, M, N, K, " | ".join(row)), flush=True)
     L.vl_debug_set(1, 0)
     L.vl_debug_set(2, 0)
-    L.vl_debug_set(3, 0)
-    L.vl_debug_set(4, 4)
-    L.vl_debug_set(6, 0)
     L.vl_debug_set(7, 1)
 
 
