@@ -35,7 +35,7 @@ int g_force_generic = 0;
 int g_pingpong = 1;   // 8-wave ping-pong kernel (key 7): 0 = off, 1 = automatic tile width, 2 / 3 = force 256 / 192, 4 = cost model only
 int g_pp3 = 1;        // key 8: 3-pass products on the ping-pong kernel too
 int g_tile224 = 1;    // key 9: allow the 224 x 256 tile
-int g_persist = 2;    // key 10: persistent ping-pong launch: 0 = never, 1 = 3-pass products only, 2 = all
+int g_persist = 1;    // key 10: persistent ping-pong launch: 0 = never, 1 = 3-pass products only, 2 = all
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -917,7 +917,9 @@ int launch3(GemmArgs a, hipStream_t stream) {
   a.tiles_m = (a.M + BMT - 1) / BMT;
   a.tiles_n = (a.N + BNT - 1) / BNT;
   // persistent launch: one workgroup per CU walks its tiles with the K-tile stream continuing across them (measured
-  // alone: -4..7 % on the 504-768-tile products; with <= 256 tiles it is one tile per workgroup as before); key 10
+  // alone: -4..7 % on the 504-768-tile products).  Only for the forward (3-pass) products: the 1-pass backward products
+  // share the chip with the dW stream, and a static tile list per workgroup then waits for whichever CUs that stream
+  // holds (the 768-tile GELU' product went from 125 to 160 us in situ) -> one tile per workgroup there; key 10
   int grid = a.tiles_m * a.tiles_n;
   if (g_persist == 2 || (g_persist == 1 && NSPLIT == 3)) {
     static int ncu = 0;

@@ -69,7 +69,7 @@ def main():
     L.vl_debug_set(1, 0)
     L.vl_debug_set(2, 0)
     L.vl_debug_set(7, 1)
-    L.vl_debug_set(10, 2)
+    L.vl_debug_set(10, 1)
 
 
 if __name__ == "__main__":
