@@ -9,7 +9,7 @@ import re
 from ctypes import c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvlhip.so")
+LIB_PATH = os.environ.get("VLHIP_LIBRARY") or os.path.join(_HERE, "csrc", "libvlhip.so")  # override: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vlhip.h")
 
 P = c_void_p
@@ -24,6 +24,7 @@ _SIGS = {
     "vl_gemm_nt_splitk": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P]),
     "vl_gemm_tn_splitk": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P]),
     "vl_gemm_tn_grouped": (c_int, [P, c_int64, c_int64, c_int64, P]),
+    "vl_gemm_tn_splitk_to": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, c_int64, c_int, P]),
     "vl_ln_debug_blocks": (c_int, [c_int]),
     "vl_ln_bwd_reduce": (c_int, [P, c_int64, c_int64, P, P, P, P]),
     "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),

@@ -150,6 +150,9 @@ class LayerStack(object):
         self.side_reduce = False  # LayerNorm-backward column sums on the weight-gradient stream: measured +0.1 ms (that stream is the longer one)
         self.early_join = False  # A/B knob: join the streams at the end of the layer stack instead of the trunk
         self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
+        # callable(layer) -> (16 destination views in LayerSpec.params order, accumulate) or None: when the optimizer
+        # provides it, the weight-gradient GEMMs write straight into its flat gradient arena (no gradient copies)
+        self.grad_sink = None
         self._fork = None
         self.group_dw = False  # one grouped launch per layer (ops.gemm_tn_grouped): measured equal in situ, see DESIGN.md
         self._side = None
@@ -227,8 +230,23 @@ class LayerStack(object):
             finally:
                 ops.set_stream(main_ptr)
 
+        def dw_to(dy16, x16, n_out, k_in, views, accumulate, lins):
+            """Weight gradient(s) of the Linear(s) `lins` (packed along the output rows): into the optimizer's arena
+            views when there are any and the shape is on the TN fast path (-> [None, ...]), else as tensors."""
+            n = len(lins)
+            if views is not None and ops.gemm_tn_splitk_to(dy16, x16, n_out, k_in, M, views, accumulate=accumulate):
+                for v, lin in zip(views, lins):
+                    _masked(v, lin)
+                return [None] * n
+            dW = dw_gemm(dy16, x16, M, n_out, k_in)
+            rows = n_out // n
+            return [_masked(dW[i * rows:(i + 1) * rows] if n > 1 else dW, lin) for i, lin in enumerate(lins)]
+
         for l in reversed(range(len(self.specs))):
             sp, lw, ls = self.specs[l], pw_layers[l], saved[l]
+            sink = self.grad_sink(l) if (self.grad_sink is not None and self.layer_done_hook is not None) else None
+            sv_, sacc = sink if sink is not None else (None, False)
+            pick = (lambda *idx: [sv_[i] for i in idx]) if sv_ is not None else (lambda *idx: None)  # noqa: E731
             dz2, dt2 = f32(M, H), b16(M, H)
             dg2, db2, dbias2 = f32(H), f32(H), f32(H)
             # the column sums (dgamma, dbeta, the dense layer's bias gradient) are only needed by the optimizer: the
@@ -245,8 +263,8 @@ class LayerStack(object):
             du16 = b16(M, I)
             ops.gemm_nt(dt2, None, lw["w2"].t_hi, None, M, I, H, 1, EPI_DGELU_BF16, out_hi=du16, aux16=ls["u16"])
             if not grouped:
-                dW2, dW1, dbias1 = on_side(lambda: (_masked(dw_gemm(dt2, ls["h_hi"], M, H, I), sp.w2),
-                                                    _masked(dw_gemm(du16, ls["x1_hi"], M, I, H), sp.w1),
+                dW2, dW1, dbias1 = on_side(lambda: (dw_to(dt2, ls["h_hi"], H, I, pick(12), sacc, [sp.w2])[0],
+                                                    dw_to(du16, ls["x1_hi"], I, H, pick(10), sacc, [sp.w1])[0],
                                                     ops.colsum_bf16(du16, M, I, f32(I))),
                                            dt2, du16, ls["h_hi"], ls["x1_hi"])
             dx1 = f32(M, H)
@@ -262,7 +280,7 @@ class LayerStack(object):
                 ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, dg1, db1,
                            dbias_o, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
             if not grouped:
-                dWo = on_side(lambda: _masked(dw_gemm(dt1, ls["ctx_hi"], M, H, H), sp.o), dt1, ls["ctx_hi"])
+                dWo = on_side(lambda: dw_to(dt1, ls["ctx_hi"], H, H, pick(6), sacc, [sp.o])[0], dt1, ls["ctx_hi"])
             dctx = f32(M, H)
             ops.gemm_nt(dt1, None, lw["o"].t_hi, None, M, H, H, 1, EPI_F32, out32=dctx)
             dqkv = b16(M, 3 * H)
@@ -270,10 +288,8 @@ class LayerStack(object):
                          seed(16 * l + 3))
 
             def qkv_grads():
-                dW = dw_gemm(dqkv, ls["x_hi"], M, 3 * H, H)
-                for i, lin in enumerate((sp.q, sp.k, sp.v)):
-                    _masked(dW[i * H:(i + 1) * H], lin)
-                return dW, ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H))
+                return (dw_to(dqkv, ls["x_hi"], 3 * H, H, pick(0, 2, 4), sacc, [sp.q, sp.k, sp.v]),
+                        ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H)))
 
             def layer_grads_grouped():
                 # the layer's six weight gradients in ONE launch (no split-K slabs); SFT masks ride in the epilogue
@@ -290,11 +306,12 @@ class LayerStack(object):
             if grouped:
                 dWqkv, dbqkv, dWo, dW1, dbias1, dW2 = on_side(layer_grads_grouped, dqkv, dt1, du16, dt2, ls["x_hi"],
                                                               ls["ctx_hi"], ls["x1_hi"], ls["h_hi"])
+                dWq, dWk, dWv = dWqkv[0:H], dWqkv[H:2 * H], dWqkv[2 * H:]
             else:
-                dWqkv, dbqkv = on_side(qkv_grads, dqkv, ls["x_hi"])
+                (dWq, dWk, dWv), dbqkv = on_side(qkv_grads, dqkv, ls["x_hi"])
             dx0 = f32(M, H)
             ops.gemm_nt(dqkv, None, lw["qkv"].t_hi, None, M, H, 3 * H, 1, EPI_F32, resid=dz1, out32=dx0)
-            layer_grads[l] = [dWqkv[0:H], dbqkv[0:H], dWqkv[H:2 * H], dbqkv[H:2 * H], dWqkv[2 * H:], dbqkv[2 * H:],
+            layer_grads[l] = [dWq, dbqkv[0:H], dWk, dbqkv[H:2 * H], dWv, dbqkv[2 * H:],
                               dWo, dbias_o, dg1, db1, dW1, dbias1, dW2, dbias2, dg2, db2]
             if self.layer_done_hook is not None:
                 # multi-GPU: the optimizer takes this layer's gradients now (copy into its flat arena + asynchronous
@@ -302,7 +319,7 @@ class LayerStack(object):
                 # (the gradient tensors go into `keep`: the hook's copy kernels read them on the other stream after
                 # this frame has dropped its references)
                 if on_side(lambda: self.layer_done_hook(l, layer_grads[l], side if side is not None else main),
-                           *layer_grads[l]):
+                           *[g for g in layer_grads[l] if g is not None]):
                     layer_grads[l] = [None] * len(layer_grads[l])
             dy = dx0
             saved[l] = None  # release this layer's activations (side-stream operands stay alive through `keep`)

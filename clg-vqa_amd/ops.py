@@ -111,6 +111,28 @@ def gemm_tn_splitk(a, b, M, N, K, out32, splits=None):
     return True
 
 
+def gemm_tn_splitk_to(a, b, M, N, K, outs, accumulate=False, splits=None):
+    """outs[t] (+)= rows [t*M/len(outs), ...) of A[K,M]^T . B[K,N]: the weight gradient written straight into (views of)
+    the optimizer's gradient arena.  Returns False when the shape is outside the TN fast path."""
+    import ctypes
+    L = _lib.lib()
+    if splits is None:
+        splits = L.vl_gemm_splitk_plan(M, N, K)
+    ws = _tmp(torch.empty(M * N * splits, dtype=torch.float32, device=a.device))
+    pa, lda = _pld(a)
+    pb, ldb = _pld(b)
+    n = len(outs)
+    for o in outs:
+        assert o.is_contiguous() and o.dtype == torch.float32 and o.numel() == (M // n) * N
+    arr = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
+    rc = L.vl_gemm_tn_splitk_to(pa, lda, pb, ldb, M, N, K, splits, _p(ws), ctypes.cast(arr, ctypes.c_void_p), n,
+                                1 if accumulate else 0, _stream())
+    if rc == -2:
+        return False
+    _lib.check(rc, "vl_gemm_tn_splitk_to")
+    return True
+
+
 def gemm_tn_grouped(problems, K, splits=0):
     """One launch for several weight-gradient products sharing the batch dimension K:
     problems = [(a [K,M] bf16, b [K,N] bf16, out [M,N] fp32, mask [M,N] fp32 or None), ...]  ->  out = a^T b (* mask)."""

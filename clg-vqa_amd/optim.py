@@ -224,12 +224,22 @@ class FusedAdamW(object):
                 plan.append((idx, [self.arena.grad_views[i] for i in idx], ranges))
             self._layer_plan = plan
             eng.stack.layer_done_hook = self._on_layer_grads
+            eng.stack.grad_sink = self._sink_for_layer
 
     def set_overlap(self, enabled):
         """Switch the during-backward gradient exchange on / off (off: everything is reduced inside step())."""
         eng = getattr(self.model, "engine", None)
         if eng is not None and hasattr(eng, "stack"):
             eng.stack.layer_done_hook = self._on_layer_grads if (enabled and self._layer_plan is not None) else None
+
+    def _sink_for_layer(self, layer):
+        """Destination views (LayerSpec.params order) for the layer's weight-gradient GEMMs + whether they must add to
+        what an earlier backward of this step left there."""
+        plan = self._layer_plan[layer]
+        if plan is None:
+            return None
+        idx, views, _ = plan
+        return views, bool(self._pre.intersection(idx))
 
     def _on_layer_grads(self, layer, grads, stream):
         plan = self._layer_plan[layer]
@@ -241,11 +251,14 @@ class FusedAdamW(object):
             raise RuntimeError("clg_vqa_amd.FusedAdamW: a second backward arrived before step(); construct the optimizer "
                                "with overlap_reduce=False when accumulating gradients over micro-batches")
         with torch.cuda.stream(stream):  # behind this layer's weight-gradient kernels
-            src = [g.view_as(v) for g, v in zip(grads, views)]
+            # (None = the GEMM already wrote that gradient into its arena view: the six weight matrices, 99.9 % of
+            # the layer's gradient bytes; what is copied here are the ten bias / LayerNorm vectors)
+            dst = [v for g, v in zip(grads, views) if g is not None]
+            src = [g.view_as(v) for g, v in zip(grads, views) if g is not None]
             if again:  # one GPU, gradient accumulation: add to what the earlier backward left in the arena
-                torch._foreach_add_(views, src)
+                torch._foreach_add_(dst, src)
             else:
-                torch._foreach_copy_(views, src)
+                torch._foreach_copy_(dst, src)
             if self.reducer.world_size() > 1:
                 self._works += self.reducer.allreduce_async(self.arena.grad, ranges)
         self._pre.update(idx)

@@ -65,6 +65,12 @@ int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi, int64_t l
  * the fast path (K % 64, M >= 256, N >= 128, M/N multiples of 8): use vl_transpose_bf16 + vl_gemm_nt_splitk then. */
 int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float* ws, float* out32, void* stream);
+/* ... with the rows of the result scattered over nout (1..4) contiguous destinations (`outs`: HOST array of device
+ * pointers; rows [t*M/nout, (t+1)*M/nout) -> outs[t]), added to their contents when accumulate != 0: the engine points
+ * them at the optimizer's flat gradient arena (packed Q/K/V gradient -> three parameters) instead of copying gradients.
+ * ws: splits*M*N floats even for splits == 1. */
+int vl_gemm_tn_splitk_to(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                         int64_t splits, float* ws, float* const* outs, int64_t nout, int accumulate, void* stream);
 
 /* Grouped form of the same product (the four dW GEMMs of one transformer layer in ONE launch, no split-K slabs):
  * for each problem p, out_p[M_p, N_p] = A_p^T B_p (* mask_p) with A_p [K, M_p], B_p [K, N_p] row-major bf16 and K
