@@ -35,7 +35,6 @@ int g_force_generic = 0;
 int g_pingpong = 1;   // 8-wave ping-pong kernel (key 7): 0 = off, 1 = automatic tile width, 2 / 3 = force 256 / 192, 4 = cost model only
 int g_pp3 = 1;        // key 8: 3-pass products on the ping-pong kernel too
 int g_tile224 = 1;    // key 9: allow the 224 x 256 tile
-int g_persist = 1;    // key 10: persistent ping-pong launch: 0 = never, 1 = 3-pass products only, 2 = all
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -400,74 +399,45 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   const int wr = wave / WC, wc = wave % WC;
   const bool late = wave >= 4;  // the wave group that runs one barrier behind
 
-  // Persistent over tiles: workgroup `bid` takes the virtual block ids bid, bid + G, bid + 2G, ... (G = gridDim.x; with
-  // G = number of tiles this is one tile per workgroup) and the K-tile stream simply continues across tiles: the last
-  // phases of a tile already stage the first K-tiles of the next one, so the HBM/L2 latency of a tile's first loads
-  // and the epilogue's store drain overlap instead of costing a prologue per tile (K = 768: 12-24 K-tiles per tile).
-  // Virtual block id -> tile: blocks that share an XCD (id % 8) walk a contiguous chunk of the tile list (bijective).
   const int nwg = p.tiles_m * p.tiles_n;
-  const int G = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = swz / p.tiles_n, tn = swz - tm * p.tiles_n;
+  const int row0 = tm * BMT, col0 = tn * BNT;
   const int nk = p.K / KSTEP;
-  auto tile_of = [&](int v, int& tm_, int& tn_) {
-    const int xcd = v & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (v >> 3);
-    tm_ = swz / p.tiles_n;
-    tn_ = swz - tm_ * p.tiles_n;
-  };
 
-  // DMA sources, one stream per half-tile type x in {A0, A1, B0, B1}: unit u = wave + 8*j (8 rows x 128 B), lane ->
-  // (row, physical chunk); the pointers advance one K-tile per issue and hop to the next tile of this workgroup after
-  // the last K-tile.  ik = next K-tile index, iv = virtual block the pointers belong to, sq = stage parity of the
-  // next issue (all wave-uniform).
+  // DMA sources: half-tile x in {A0, A1, B0, B1}; unit u = wave + 8*j (8 rows x 128 B); lane -> (row, physical chunk)
   const bf16_raw* src[4][2];
-  int ik[4], iv[4], sq[4];
-#define G3_SETUP(x, v)                                                                                           \
-  do {                                                                                                           \
-    int tm_, tn_;                                                                                                \
-    tile_of((v), tm_, tn_);                                                                                      \
-    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                           \
-      constexpr bool isB = (x) >= 2;                                                                             \
-      const int r = 8 * (wave + 8 * j_) + (lane >> 3);                                                           \
-      const int lc = (lane & 7) ^ swz3(r); /* logical chunk that lands at physical position lane & 7 */          \
-      int g_ = (isB ? tn_ * BNT + ((x) & 1) * BH : tm_ * BMT + ((x) & 1) * AH) + r;                              \
-      const int lim = (isB ? p.N : p.M) - 1;                                                                     \
-      g_ = g_ < lim ? g_ : lim; /* rows past the edge re-read a valid row; their products are never stored */    \
-      const bf16_raw* base;                                                                                      \
-      int koff;                                                                                                  \
-      if (NSPLIT == 3) {                                                                                         \
-        base = isB ? ((lc & 4) ? p.b_lo : p.b_hi) : ((lc & 4) ? p.a_lo : p.a_hi);                                \
-        koff = (lc & 3) * 8;                                                                                     \
-      } else {                                                                                                   \
-        base = isB ? p.b_hi : p.a_hi;                                                                            \
-        koff = lc * 8;                                                                                           \
-      }                                                                                                          \
-      src[x][j_] = base + (long)g_ * (isB ? p.ldb : p.lda) + koff;                                               \
-    }                                                                                                            \
-  } while (0)
 #pragma unroll
-  for (int x = 0; x < 4; ++x) { ik[x] = 0; iv[x] = blockIdx.x; sq[x] = 0; }
-  G3_SETUP(0, blockIdx.x); G3_SETUP(1, blockIdx.x); G3_SETUP(2, blockIdx.x); G3_SETUP(3, blockIdx.x);
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool isB = x >= 2;
+      const int r = 8 * (wave + 8 * j) + (lane >> 3);
+      const int lc = (lane & 7) ^ swz3(r);  // logical chunk that lands at physical position lane & 7
+      int g = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + r;
+      const int lim = (isB ? p.N : p.M) - 1;
+      g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
+      const bf16_raw* base;
+      int koff;
+      if (NSPLIT == 3) {
+        base = isB ? ((lc & 4) ? p.b_lo : p.b_hi) : ((lc & 4) ? p.a_lo : p.a_hi);
+        koff = (lc & 3) * 8;
+      } else {
+        base = isB ? p.b_hi : p.a_hi;
+        koff = lc * 8;
+      }
+      src[x][j] = base + (long)g * (isB ? p.ldb : p.lda) + koff;
+    }
   constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
-  bool issued;
-#define G3_ISSUE(x)                                                                                              \
+#define G3_ISSUE(x, kt)                                                                                          \
   do {                                                                                                           \
-    if (ik[x] == nk && iv[x] + G < nwg) { /* this type's stream moves on to the workgroup's next tile */         \
-      iv[x] += G;                                                                                                \
-      ik[x] = 0;                                                                                                 \
-      G3_SETUP(x, iv[x]);                                                                                        \
-    }                                                                                                            \
-    issued = ik[x] < nk;                                                                                         \
-    if (issued) {                                                                                                \
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)src[x][0],                                                     \
-                                       (lds_ptr_t)(smem + (sq[x] & 1) * STAGE + XOFF[x] + wave * 1024), 16, 0, 0); \
-      if (!(late && ((BSHORT && (x) >= 2) || (ASHORT && (x) == 1))))                                             \
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src[x][1],                                                   \
-                                         (lds_ptr_t)(smem + (sq[x] & 1) * STAGE + XOFF[x] + (wave + 8) * 1024), 16, 0, 0); \
-      src[x][0] += KSTEP;                                                                                        \
-      src[x][1] += KSTEP;                                                                                        \
-      ik[x] += 1;                                                                                                \
-      sq[x] += 1;                                                                                                \
-    }                                                                                                            \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][0] + (long)(kt) * KSTEP),                                \
+                                     (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + wave * 1024), 16, 0, 0);  \
+    if (!(late && ((BSHORT && (x) >= 2) || (ASHORT && (x) == 1))))                                               \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][1] + (long)(kt) * KSTEP),                              \
+                                       (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + (wave + 8) * 1024), 16, 0, 0); \
   } while (0)
   // wait until everything older than the youngest (nA A-half-tiles + nB B-half-tiles) has landed
 #define G3_WAIT_YOUNGER(nA, nB)                                                                                  \
@@ -482,6 +452,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   } while (0)
 
   f32x4 acc[2][2][MI][NJ];  // [1][*][i >= MI1] unused
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment byte offsets inside a half-tile: [tile][first / second 64-B half of the row], swizzle folded in
   const int frow = lane & 15, fk = lane >> 4;
@@ -542,12 +520,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     __builtin_amdgcn_s_barrier();                                                                                \
   } while (0)
 
-  // prologue: K-tile 0 complete, A0 / B0 of the next K-tile (of this or of the next tile) in flight
-  G3_ISSUE(0); G3_ISSUE(2); G3_ISSUE(3); G3_ISSUE(1);
-  G3_ISSUE(0);
-  const bool more0 = issued;
-  G3_ISSUE(2);
-  if (more0) {
+  // prologue: K-tile 0 complete, A0 / B0 of K-tile 1 in flight
+  G3_ISSUE(0, 0); G3_ISSUE(2, 0); G3_ISSUE(3, 0); G3_ISSUE(1, 0);
+  if (nk > 1) {
+    G3_ISSUE(0, 1); G3_ISSUE(2, 1);
     G3_WAIT_YOUNGER(1, 1);
   } else {
     wait_vmcnt<0>();
@@ -555,72 +531,32 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   __builtin_amdgcn_s_barrier();
   if (late) __builtin_amdgcn_s_barrier();  // stagger
 
-  int gseq = 0;  // K-tiles consumed so far: stage parity of the reads
-  for (int vb = blockIdx.x; vb < nwg; vb += G) {
-    int tm, tn;
-    tile_of(vb, tm, tn);
-    const int row0 = tm * BMT, col0 = tn * BNT;
-#pragma unroll
-    for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-      for (int b_ = 0; b_ < 2; ++b_)
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int kt = 0; kt < nk; ++kt, ++gseq) {
-      const unsigned char* st = smem + (gseq & 1) * STAGE;
-      // phase 0: quadrant (0,0); stages B1 of the next K-tile
-      G3_READ_B(st, 0, fb0);
-      __builtin_amdgcn_sched_barrier(0);
-      G3_READ_A(st, 0);
-      G3_ISSUE(3);
-      G3_WAIT(issued);
-      G3_MFMA(0, 0, fb0);
-      // phase 1: quadrant (0,1); stages A1 of the next K-tile
-      G3_READ_B(st, 1, fb1);
-      G3_ISSUE(1);
-      G3_WAIT(issued);
-      G3_MFMA(0, 1, fb1);
-      // phase 2: quadrant (1,1); stages A0 of the K-tile after the next
-      G3_READ_A(st, 1);
-      G3_ISSUE(0);
-      G3_WAIT(issued);
-      G3_MFMA(1, 1, fb1);
-      // phase 3: quadrant (1,0); stages B0 of the K-tile after the next
-      G3_ISSUE(2);
-      G3_WAIT(issued);
-      G3_MFMA(1, 0, fb0);
-    }
-
-    // epilogue (no barriers, no LDS: the next tile's first K-tiles keep landing underneath).  D^T layout: lane&15 ->
-    // m inside the 16-row tile, 4*(lane>>4) + reg -> n inside the 16-col tile
-    float* out32 = p.out32;
-#pragma unroll
-    for (int qm = 0; qm < 2; ++qm)
-#pragma unroll
-      for (int i = 0; i < (qm == 0 ? MI : MI1); ++i) {
-        const int m = row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int qn = 0; qn < 2; ++qn)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) {
-            const int cb = col0 + qn * BH + wc * (NJ * 16);
-            if (j < NJP) {
-              if (j & 1) continue;
-              const int n0 = cb + 32 * (j >> 1) + 8 * (lane >> 4);
-              if (n0 < p.N) epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j]);
-            } else {
-              const int n0 = cb + j * 16 + 4 * (lane >> 4);
-              if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j]);
-            }
-          }
-      }
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    // phase 0: quadrant (0,0)
+    G3_READ_B(st, 0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    G3_READ_A(st, 0);
+    if (n1) G3_ISSUE(3, kt + 1);
+    G3_WAIT(n1);
+    G3_MFMA(0, 0, fb0);
+    // phase 1: quadrant (0,1)
+    G3_READ_B(st, 1, fb1);
+    if (n1) G3_ISSUE(1, kt + 1);
+    G3_WAIT(n1);
+    G3_MFMA(0, 1, fb1);
+    // phase 2: quadrant (1,1)
+    G3_READ_A(st, 1);
+    if (n2) G3_ISSUE(0, kt + 2);
+    G3_WAIT(n2);
+    G3_MFMA(1, 1, fb1);
+    // phase 3: quadrant (1,0)
+    if (n2) G3_ISSUE(2, kt + 2);
+    G3_WAIT(n2);
+    G3_MFMA(1, 0, fb0);
   }
   if (!late) __builtin_amdgcn_s_barrier();  // matches the stagger barrier
-#undef G3_SETUP
 #undef G3_ISSUE
 #undef G3_WAIT_YOUNGER
 #undef G3_WAIT
@@ -628,6 +564,29 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 #undef G3_READ_B
 #undef G3_MFMA
 
+  // epilogue.  D^T layout: lane&15 -> m inside the 16-row tile, 4*(lane>>4) + reg -> n inside the 16-col tile
+  float* out32 = p.out32;
+#pragma unroll
+  for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+    for (int i = 0; i < (qm == 0 ? MI : MI1); ++i) {
+      const int m = row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane & 15);
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int cb = col0 + qn * BH + wc * (NJ * 16);
+          if (j < NJP) {
+            if (j & 1) continue;
+            const int n0 = cb + 32 * (j >> 1) + 8 * (lane >> 4);
+            if (n0 < p.N) epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j]);
+          } else {
+            const int n0 = cb + j * 16 + 4 * (lane >> 4);
+            if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j]);
+          }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -939,22 +898,7 @@ int launch3(GemmArgs a, hipStream_t stream) {
   }
   a.tiles_m = (a.M + BMT - 1) / BMT;
   a.tiles_n = (a.N + BNT - 1) / BNT;
-  // persistent launch: one workgroup per CU walks its tiles with the K-tile stream continuing across them (measured
-  // alone: -4..7 % on the 504-768-tile products).  Only for the forward (3-pass) products: the 1-pass backward products
-  // share the chip with the dW stream, and a static tile list per workgroup then waits for whichever CUs that stream
-  // holds (the 768-tile GELU' product went from 125 to 160 us in situ) -> one tile per workgroup there; key 10
-  int grid = a.tiles_m * a.tiles_n;
-  if (g_persist == 2 || (g_persist == 1 && NSPLIT == 3)) {
-    static int ncu = 0;
-    if (!ncu) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-      if (ncu <= 0) ncu = 256;
-    }
-    if (grid > ncu) grid = ncu & ~7;  // a multiple of 8 keeps the virtual block id -> XCD relation
-  }
-  hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, CFG>), dim3(grid), dim3(512), lds, stream, a);
+  hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt(ping-pong)");
   return 0;
 }
@@ -1126,14 +1070,13 @@ extern "C" int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi
 
 // A/B knobs for benchmarking (not part of the drop-in surface): 1 = BN of the single-barrier kernel (0 = auto),
 // 2 = force the generic 128x128 kernel, 7 = ping-pong kernel (0 off, 1 auto, 2 / 3 / 5 = force 256x256 / 256x192 /
-// 224x256 tiles, 4 = cost model only), 8 = ping-pong for 3-pass products, 9 = allow the 224x256 tile, 10 = persistent launch (0 never, 1 = 3-pass, 2 = all).
+// 224x256 tiles, 4 = cost model only), 8 = ping-pong for 3-pass products, 9 = allow the 224x256 tile.
 extern "C" int vl_debug_set(int key, int value) {
   if (key == 1) g_force_bn = value;
   else if (key == 2) g_force_generic = value;
   else if (key == 7) g_pingpong = value;
   else if (key == 8) g_pp3 = value;
   else if (key == 9) g_tile224 = value;
-  else if (key == 10) g_persist = value;
   else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
   return 0;
 }

@@ -30,9 +30,8 @@ def main():
     L = _lib.lib()
     shapes = [("qkv   fwd", 14336, 2304, 768), ("oproj fwd", 14336, 768, 768), ("ffn1  fwd", 14336, 3072, 768),
               ("ffn2  fwd", 14336, 768, 3072), ("qkv   dX ", 14336, 768, 2304)]
-    variants = [("old-256", dict(g=0, bn=256, pp=0)), ("pp-256", dict(g=0, bn=0, pp=2, ps=0)),
-                ("pp-256-persist", dict(g=0, bn=0, pp=2, ps=2)), ("pp-192", dict(g=0, bn=0, pp=3, ps=0)),
-                ("pp-192-persist", dict(g=0, bn=0, pp=3, ps=2))]
+    variants = [("old-256", dict(g=0, bn=256, pp=0)), ("old-192", dict(g=0, bn=192, pp=0)),
+                ("pp-256", dict(g=0, bn=0, pp=2)), ("pp-192", dict(g=0, bn=0, pp=3))]
     for passes in (1, 3):
         print("== passes %d ==" % passes)
         for name, M, N, K in shapes:
@@ -51,7 +50,6 @@ def main():
                 L.vl_debug_set(2, v["g"])
                 L.vl_debug_set(1, v["bn"])
                 L.vl_debug_set(7, v.get("pp", 0))
-                L.vl_debug_set(10, v.get("ps", 0))
                 def run():
                     it[0] += 1
                     ops.gemm_nt(a_list[it[0] % nbuf], al_list[it[0] % len(al_list)], b, bl, M, N, K, passes, EPI_F32,
@@ -69,7 +67,6 @@ def main():
     L.vl_debug_set(1, 0)
     L.vl_debug_set(2, 0)
     L.vl_debug_set(7, 1)
-    L.vl_debug_set(10, 1)
 
 
 if __name__ == "__main__":
