@@ -49,6 +49,14 @@ __device__ __forceinline__ float gelu_erf(float x) {
   vl_cdf_pdf(x, cdf, e);
   return x * cdf;
 }
+// value and derivative together (the forward epilogue stores the derivative for the backward pass: one fma more there,
+// ~25 VALU ops per element less in the GELU' epilogue of the backward GEMM)
+__device__ __forceinline__ void gelu_erf_both(float x, float& y, float& dy) {
+  float cdf, e;
+  vl_cdf_pdf(x, cdf, e);
+  y = x * cdf;
+  dy = fmaf(x * 0.3989422804014327f, e, cdf);
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   float cdf, e;
   vl_cdf_pdf(x, cdf, e);

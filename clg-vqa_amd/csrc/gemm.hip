@@ -81,18 +81,21 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
       ushort4 hi, lo;
       if (EPI == VL_EPI_GELU_SPLIT) {
         ushort4 u;
-        u.x = f32_to_bf16(v[0]); u.y = f32_to_bf16(v[1]); u.z = f32_to_bf16(v[2]); u.w = f32_to_bf16(v[3]);
+        float y[4], d[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gelu_erf_both(v[t], y[t], d[t]);
+        u.x = f32_to_bf16(d[0]); u.y = f32_to_bf16(d[1]); u.z = f32_to_bf16(d[2]); u.w = f32_to_bf16(d[3]);
         *reinterpret_cast<ushort4*>(p.aux16 + o) = u;
-        split_bf16(gelu_erf(v[0]), hi.x, lo.x); split_bf16(gelu_erf(v[1]), hi.y, lo.y);
-        split_bf16(gelu_erf(v[2]), hi.z, lo.z); split_bf16(gelu_erf(v[3]), hi.w, lo.w);
+        split_bf16(y[0], hi.x, lo.x); split_bf16(y[1], hi.y, lo.y);
+        split_bf16(y[2], hi.z, lo.z); split_bf16(y[3], hi.w, lo.w);
         *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
         *reinterpret_cast<ushort4*>(p.out_lo + o) = lo;
       } else if (EPI == VL_EPI_DGELU_BF16) {
         const ushort4 u = *reinterpret_cast<const ushort4*>(p.aux16 + o);
-        hi.x = f32_to_bf16(v[0] * gelu_erf_grad(bf16_to_f32(u.x)));
-        hi.y = f32_to_bf16(v[1] * gelu_erf_grad(bf16_to_f32(u.y)));
-        hi.z = f32_to_bf16(v[2] * gelu_erf_grad(bf16_to_f32(u.z)));
-        hi.w = f32_to_bf16(v[3] * gelu_erf_grad(bf16_to_f32(u.w)));
+        hi.x = f32_to_bf16(v[0] * bf16_to_f32(u.x));
+        hi.y = f32_to_bf16(v[1] * bf16_to_f32(u.y));
+        hi.z = f32_to_bf16(v[2] * bf16_to_f32(u.z));
+        hi.w = f32_to_bf16(v[3] * bf16_to_f32(u.w));
         *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
       } else if (EPI == VL_EPI_BF16) {
         hi.x = f32_to_bf16(v[0]); hi.y = f32_to_bf16(v[1]); hi.z = f32_to_bf16(v[2]); hi.w = f32_to_bf16(v[3]);
@@ -115,14 +118,16 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
       if (p.resid) x += p.resid[(long)m * p.ldc + n];
       out32[(long)m * p.ldc + n] = x;
     } else if (EPI == VL_EPI_GELU_SPLIT) {
-      p.aux16[(long)m * p.ld16 + n] = f32_to_bf16(x);
+      float y, d;
+      gelu_erf_both(x, y, d);
+      p.aux16[(long)m * p.ld16 + n] = f32_to_bf16(d);
       bf16_raw hi, lo;
-      split_bf16(gelu_erf(x), hi, lo);
+      split_bf16(y, hi, lo);
       p.out_hi[(long)m * p.ld16 + n] = hi;
       p.out_lo[(long)m * p.ld16 + n] = lo;
     } else if (EPI == VL_EPI_DGELU_BF16) {
       const float u = bf16_to_f32(p.aux16[(long)m * p.ld16 + n]);
-      p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(x * gelu_erf_grad(u));
+      p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(x * u);
     } else if (EPI == VL_EPI_BF16) {
       p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(x);
     } else {
@@ -157,13 +162,16 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32,
   ushort4 h0, h1, l0, l1;
   if (EPI == VL_EPI_GELU_SPLIT) {
     ushort4 u0, u1;
-    u0.x = f32_to_bf16(x[0]); u0.y = f32_to_bf16(x[1]); u0.z = f32_to_bf16(x[2]); u0.w = f32_to_bf16(x[3]);
-    u1.x = f32_to_bf16(x[4]); u1.y = f32_to_bf16(x[5]); u1.z = f32_to_bf16(x[6]); u1.w = f32_to_bf16(x[7]);
+    float y[8], d[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) gelu_erf_both(x[t], y[t], d[t]);
+    u0.x = f32_to_bf16(d[0]); u0.y = f32_to_bf16(d[1]); u0.z = f32_to_bf16(d[2]); u0.w = f32_to_bf16(d[3]);
+    u1.x = f32_to_bf16(d[4]); u1.y = f32_to_bf16(d[5]); u1.z = f32_to_bf16(d[6]); u1.w = f32_to_bf16(d[7]);
     *reinterpret_cast<uint4*>(p.aux16 + o) = pack8(u0, u1);
-    split_bf16(gelu_erf(x[0]), h0.x, l0.x); split_bf16(gelu_erf(x[1]), h0.y, l0.y);
-    split_bf16(gelu_erf(x[2]), h0.z, l0.z); split_bf16(gelu_erf(x[3]), h0.w, l0.w);
-    split_bf16(gelu_erf(x[4]), h1.x, l1.x); split_bf16(gelu_erf(x[5]), h1.y, l1.y);
-    split_bf16(gelu_erf(x[6]), h1.z, l1.z); split_bf16(gelu_erf(x[7]), h1.w, l1.w);
+    split_bf16(y[0], h0.x, l0.x); split_bf16(y[1], h0.y, l0.y);
+    split_bf16(y[2], h0.z, l0.z); split_bf16(y[3], h0.w, l0.w);
+    split_bf16(y[4], h1.x, l1.x); split_bf16(y[5], h1.y, l1.y);
+    split_bf16(y[6], h1.z, l1.z); split_bf16(y[7], h1.w, l1.w);
     *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
     *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
   } else if (EPI == VL_EPI_DGELU_BF16) {
@@ -172,8 +180,8 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32,
     bf16_raw r[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      r[2 * t] = f32_to_bf16(x[2 * t] * gelu_erf_grad(bf16_to_f32((bf16_raw)(w[t] & 0xFFFFu))));
-      r[2 * t + 1] = f32_to_bf16(x[2 * t + 1] * gelu_erf_grad(bf16_to_f32((bf16_raw)(w[t] >> 16))));
+      r[2 * t] = f32_to_bf16(x[2 * t] * __uint_as_float(w[t] << 16));
+      r[2 * t + 1] = f32_to_bf16(x[2 * t + 1] * __uint_as_float(w[t] & 0xFFFF0000u));
     }
     h0.x = r[0]; h0.y = r[1]; h0.z = r[2]; h0.w = r[3]; h1.x = r[4]; h1.y = r[5]; h1.z = r[6]; h1.w = r[7];
     *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);

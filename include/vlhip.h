@@ -43,8 +43,8 @@ int vl_debug_set(int key, int value); /* A/B knobs for benchmarking (not part of
  * ------------------------------------------------------------------------------------------------------------ */
 enum {
   VL_EPI_F32 = 0,        /* out32[m,n]  = acc + bias[n] (bias may be NULL) + resid32[m,n] (may be NULL)           */
-  VL_EPI_GELU_SPLIT = 1, /* u = acc+bias; aux16 = bf16(u); (out_hi,out_lo) = split(gelu_erf(u))                   */
-  VL_EPI_DGELU_BF16 = 2, /* out_hi = bf16(acc * gelu_erf'(aux16[m,n]))   (backward through FFN1's activation)      */
+  VL_EPI_GELU_SPLIT = 1, /* u = acc+bias; aux16 = bf16(gelu_erf'(u)); (out_hi,out_lo) = split(gelu_erf(u))          */
+  VL_EPI_DGELU_BF16 = 2, /* out_hi = bf16(acc * aux16[m,n]), aux16 = the derivative saved by GELU_SPLIT (FFN1 backward) */
   VL_EPI_BF16 = 3,       /* out_hi = bf16(acc + bias)                                                             */
   VL_EPI_SPLIT = 4       /* (out_hi,out_lo) = split(acc + bias)                                                   */
 };
