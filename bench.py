@@ -220,8 +220,8 @@ def main():
             mask = (torch.rand(w.shape, generator=gen) < 0.59).float().to(dev)
             w.data.mul_(mask)
             prune.CustomFromMask.apply(mods[n], "weight", mask=mask)
-    if os.environ.get("BENCH_SIDE_REDUCE", "1") == "0":
-        model.engine.stack.side_reduce = False
+    if os.environ.get("BENCH_PAIR_REDUCE", "1") == "0":
+        model.engine.stack.pair_reduce = False
     if os.environ.get("BENCH_EARLY_JOIN", "0") == "1":
         model.engine.stack.early_join = True
     if os.environ.get("BENCH_GROUP_DW", "0") == "1":  # A/B: one grouped weight-gradient launch per layer

@@ -27,6 +27,7 @@ _SIGS = {
     "vl_gemm_tn_splitk_to": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, c_int64, c_int, P]),
     "vl_ln_debug_blocks": (c_int, [c_int]),
     "vl_ln_bwd_reduce": (c_int, [P, c_int64, c_int64, P, P, P, P]),
+    "vl_ln_bwd_reduce2": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, c_int64, P]),
     "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_ln_fwd": (c_int, [P, P, P, c_int64, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64,

@@ -192,15 +192,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
   }
 }
 
-// out_k[c] = sum_blk ws[blk][k][c]; 256 threads = 16 columns x 16 row-groups, LDS combine
-__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int H,
-                                                            float* dgamma, float* dbeta, float* dbias) {
+// out_k[c] = sum_blk ws[blk][k][c]; 256 threads = 16 columns x 16 row-groups, LDS combine.  blockIdx.y selects one
+// of up to two independent reductions (the two LayerNorms of a transformer layer share one launch).
+struct LnReduceSet { const float* ws; int nblk; float* dgamma; float* dbeta; float* dbias; };
+struct LnReduceArgs { LnReduceSet set[2]; int H; };
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(LnReduceArgs a) {
   __shared__ float red[16][17];
+  const LnReduceSet& r = a.set[blockIdx.y];
+  const int H = a.H;
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int idx = blockIdx.x * 16 + tx;  // column in [0, 3H)
   float s = 0.f;
   if (idx < 3 * H)
-    for (int b = ty; b < nblk; b += 16) s += ws[(long)b * 3 * H + idx];
+    for (int b = ty; b < r.nblk; b += 16) s += r.ws[(long)b * 3 * H + idx];
   red[ty][tx] = s;
   __syncthreads();
   if (ty == 0 && idx < 3 * H) {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
 #pragma unroll
     for (int j = 0; j < 16; ++j) t += red[j][tx];
     const int k = idx / H, c = idx - k * H;
-    float* dst = k == 0 ? dgamma : (k == 1 ? dbeta : dbias);
+    float* dst = k == 0 ? r.dgamma : (k == 1 ? r.dbeta : r.dbias);
     if (dst) dst[c] = t;
   }
 }
@@ -234,8 +238,10 @@ int launch_bwd(const LnArgs& a, hipStream_t s, float* dgamma, float* dbeta, floa
   hipLaunchKernelGGL((ln_bwd_kernel<NV>), dim3(a.nblk), dim3(256), 0, s, a);
   VL_CHECK_LAUNCH("vl_ln_bwd");
   if (!dgamma && !dbeta && !dbias) return 0;  // partials only: the caller sums them with vl_ln_bwd_reduce
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * a.H + 15) / 16), dim3(256), 0, s, a.ws, a.nblk, a.H,
-                     dgamma, dbeta, dbias);
+  LnReduceArgs ra{};
+  ra.set[0] = LnReduceSet{a.ws, a.nblk, dgamma, dbeta, dbias};
+  ra.H = a.H;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((3 * a.H + 15) / 16, 1), dim3(256), 0, s, ra);
   VL_CHECK_LAUNCH("vl_ln_bwd(reduce)");
   return 0;
 }
@@ -309,8 +315,25 @@ extern "C" int vl_ln_bwd_reduce(const float* partial_ws, int64_t M, int64_t H, f
                                 float* dbias, void* stream) {
   if (int rc = check_shape("vl_ln_bwd_reduce", M, H, 1, 0.f, 0.f)) return rc;
   VL_CHECK_ARG(partial_ws, "vl_ln_bwd_reduce: null workspace");
-  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((3 * H + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
-                     partial_ws, nblk_for(M), (int)H, dgamma, dbeta, dbias);
+  LnReduceArgs ra{};
+  ra.set[0] = LnReduceSet{partial_ws, nblk_for(M), dgamma, dbeta, dbias};
+  ra.H = (int)H;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((3 * H + 15) / 16), 1), dim3(256), 0, (hipStream_t)stream, ra);
   VL_CHECK_LAUNCH("vl_ln_bwd_reduce");
+  return 0;
+}
+
+// Two such reductions in one launch (the two LayerNorms of a transformer layer: 12 launches of ~20 us less per step).
+extern "C" int vl_ln_bwd_reduce2(const float* ws_a, int64_t M_a, float* dgamma_a, float* dbeta_a, float* dbias_a,
+                                 const float* ws_b, int64_t M_b, float* dgamma_b, float* dbeta_b, float* dbias_b,
+                                 int64_t H, void* stream) {
+  if (int rc = check_shape("vl_ln_bwd_reduce2", M_a, H, 1, 0.f, 0.f)) return rc;
+  VL_CHECK_ARG(ws_a && ws_b && M_b > 0, "vl_ln_bwd_reduce2: bad arguments");
+  LnReduceArgs ra{};
+  ra.set[0] = LnReduceSet{ws_a, nblk_for(M_a), dgamma_a, dbeta_a, dbias_a};
+  ra.set[1] = LnReduceSet{ws_b, nblk_for(M_b), dgamma_b, dbeta_b, dbias_b};
+  ra.H = (int)H;
+  hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((3 * H + 15) / 16), 2), dim3(256), 0, (hipStream_t)stream, ra);
+  VL_CHECK_LAUNCH("vl_ln_bwd_reduce2");
   return 0;
 }

@@ -148,6 +148,7 @@ class LayerStack(object):
         self.overlap_dw = True
         self._pending = None
         self.side_reduce = False  # LayerNorm-backward column sums on the weight-gradient stream: measured +0.1 ms (that stream is the longer one)
+        self.pair_reduce = True  # the two LayerNorm-backward column-sum reductions of a layer share one launch
         self.early_join = False  # A/B knob: join the streams at the end of the layer stack instead of the trunk
         self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
         # callable(layer) -> (16 destination views in LayerSpec.params order, accumulate) or None: when the optimizer
@@ -208,6 +209,8 @@ class LayerStack(object):
         # one grouped weight-gradient launch per layer needs B*S % 64 == 0 and 8-aligned feature sizes
         grouped = self.group_dw and M % 64 == 0 and H % 8 == 0 and I % 8 == 0
         defer_red = side is not None and self.side_reduce
+        pair_red = self.pair_reduce and not defer_red
+        ws_b = ops.ln_bwd_ws(M, H, dev) if pair_red else None  # second workspace: both sets of partials are live
 
         main_ptr = main.cuda_stream
         side_ptr = side.cuda_stream if side is not None else None
@@ -257,6 +260,9 @@ class LayerStack(object):
                 ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, None, None,
                            None, ws2, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
                 on_side(lambda: ops.ln_bwd_reduce(ws2, M, H, dg2, db2, dbias2), ws2)
+            elif pair_red:  # partials only; summed together with the attention sub-layer's LayerNorm below
+                ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, None, None,
+                           None, ws_b, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
             else:
                 ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, dg2, db2,
                            dbias2, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
@@ -276,6 +282,10 @@ class LayerStack(object):
                 ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, None, None,
                            None, ws1, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
                 on_side(lambda: ops.ln_bwd_reduce(ws1, M, H, dg1, db1, dbias_o), ws1)
+            elif pair_red:  # one launch sums the partials of both LayerNorms of the layer
+                ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, None, None,
+                           None, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
+                ops.ln_bwd_reduce2(ws_b, M, (dg2, db2, dbias2), ws, M, (dg1, db1, dbias_o), H)
             else:
                 ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, dg1, db1,
                            dbias_o, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))

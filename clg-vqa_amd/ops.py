@@ -189,6 +189,13 @@ def ln_bwd_reduce(ws, M, H, dgamma, dbeta, dbias):
     _lib.check(_lib.lib().vl_ln_bwd_reduce(_p(ws), M, H, _p(dgamma), _p(dbeta), _p(dbias), _stream()), "vl_ln_bwd_reduce")
 
 
+def ln_bwd_reduce2(ws_a, M_a, outs_a, ws_b, M_b, outs_b, H):
+    """Both column-sum reductions of a transformer layer in one launch; outs = (dgamma, dbeta, dbias)."""
+    _lib.check(_lib.lib().vl_ln_bwd_reduce2(_p(ws_a), M_a, _p(outs_a[0]), _p(outs_a[1]), _p(outs_a[2]), _p(ws_b), M_b,
+                                            _p(outs_b[0]), _p(outs_b[1]), _p(outs_b[2]), H, _stream()),
+               "vl_ln_bwd_reduce2")
+
+
 def mask_mul(a, m, out):
     """out = a (*) m : SFT weight_orig * weight_mask and grad (*) mask."""
     assert a.numel() == m.numel() == out.numel()

@@ -136,6 +136,10 @@ int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const floa
  * stream ordered after that call (the engine uses the weight-gradient stream: off the backward critical path). */
 int vl_ln_bwd_reduce(const float* partial_ws, int64_t M, int64_t H, float* dgamma, float* dbeta, float* dbias,
                      void* stream);
+/* two independent reductions in one launch (the two LayerNorms of a transformer layer) */
+int vl_ln_bwd_reduce2(const float* ws_a, int64_t M_a, float* dgamma_a, float* dbeta_a, float* dbias_a,
+                      const float* ws_b, int64_t M_b, float* dgamma_b, float* dbeta_b, float* dbias_b, int64_t H,
+                      void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Sparse fine-tuning mask kernels.
