@@ -358,7 +358,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     if (row_flags && i >= fl_beg4 && i < fl_end4 && !row_flags[(i - fl_beg4) / fl_row4]) {
       // embedding row that never received a gradient: g = m = v = 0, so the AdamW update is exactly p *= decay
       // (m, v, g stay 0).  Touch 8 B/param instead of 32 B/param -- bit-identical to the dense path.
-      if (wd > 0.f && lr != 0.f) {
+      // (with the reference's hyper-parameters lr * wd = 4e-5 * 1e-4 = 4e-9 is below half an fp32 ulp of 1, so `decay`
+      // IS 1.0f and the multiply -- like the reference's p.add_(-lr * wd, p) -- changes no bit: skip the 8 B/param too)
+      if (wd > 0.f && lr != 0.f && decay != 1.0f) {
         float4 pp = reinterpret_cast<float4*>(p)[i];
         pp.x *= decay; pp.y *= decay; pp.z *= decay; pp.w *= decay;
         reinterpret_cast<float4*>(p)[i] = pp;
