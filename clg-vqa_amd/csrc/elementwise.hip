@@ -348,25 +348,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   const float gs = gscale_ptr ? *gscale_ptr : gscale_const;
   const float c1 = 1.f - b1, c2 = 1.f - b2;
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    int lo = 0, hi = nseg - 1;  // first segment whose end > i
+  auto seg_of = [&](long i) {  // first segment whose end > i
+    int lo = 0, hi = nseg - 1;
     while (lo < hi) {
       const int mid = (lo + hi) >> 1;
       if (s_end4[mid] > i) hi = mid; else lo = mid + 1;
     }
-    const float lr = s_lr[lo], wd = s_wd[lo], step = lr * bc, decay = 1.f - lr * wd;
-    if (row_flags && i >= fl_beg4 && i < fl_end4 && !row_flags[(i - fl_beg4) / fl_row4]) {
-      // embedding row that never received a gradient: g = m = v = 0, so the AdamW update is exactly p *= decay
-      // (m, v, g stay 0).  Touch 8 B/param instead of 32 B/param -- bit-identical to the dense path.
-      // (with the reference's hyper-parameters lr * wd = 4e-5 * 1e-4 = 4e-9 is below half an fp32 ulp of 1, so `decay`
-      // IS 1.0f and the multiply -- like the reference's p.add_(-lr * wd, p) -- changes no bit: skip the 8 B/param too)
-      if (wd > 0.f && lr != 0.f && decay != 1.0f) {
-        float4 pp = reinterpret_cast<float4*>(p)[i];
-        pp.x *= decay; pp.y *= decay; pp.z *= decay; pp.w *= decay;
-        reinterpret_cast<float4*>(p)[i] = pp;
-      }
-      continue;
-    }
+    return lo;
+  };
+  auto update4 = [&](long i, float lr, float wd) {
+    const float step = lr * bc, decay = 1.f - lr * wd;
     float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
 #define VL_ADAM1(c)                                          \
@@ -384,6 +375,37 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
     if (zero_grad) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  // dense part: everything outside the flagged (embedding-table) range
+  const long fl_len4 = row_flags ? fl_end4 - fl_beg4 : 0;
+  for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n4 - fl_len4; j += stride) {
+    const long i = (row_flags && j >= fl_beg4) ? j + fl_len4 : j;
+    const int sg = seg_of(i);
+    update4(i, s_lr[sg], s_wd[sg]);
+  }
+  // flagged table, one wave per row: rows that never received a gradient have g = m = v = 0, so their AdamW update is
+  // exactly p *= decay (8 B/param instead of 32 B/param, bit-identical to the dense path) -- and with the reference's
+  // hyper-parameters lr * wd = 4e-5 * 1e-4 = 4e-9 is below half an fp32 ulp of 1: `decay` IS 1.0f, the multiply (like
+  // the reference's p.add_(-lr * wd, p)) changes no bit, and such rows cost one flag byte
+  if (row_flags) {
+    const int sg = seg_of(fl_beg4);
+    const float lr = s_lr[sg], wd = s_wd[sg], decay = 1.f - lr * wd;
+    const bool noop = !(wd > 0.f && lr != 0.f && decay != 1.0f);
+    const int lane = threadIdx.x & 63;
+    const long nrows = fl_len4 / fl_row4;
+    const long nwaves = stride >> 6;
+    for (long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < nrows; row += nwaves) {
+      const long base = fl_beg4 + row * fl_row4;
+      if (row_flags[row]) {
+        for (int c = lane; c < fl_row4; c += 64) update4(base + c, lr, wd);
+      } else if (!noop) {
+        for (int c = lane; c < fl_row4; c += 64) {
+          float4 pp = reinterpret_cast<float4*>(p)[base + c];
+          pp.x *= decay; pp.y *= decay; pp.z *= decay; pp.w *= decay;
+          reinterpret_cast<float4*>(p)[base + c] = pp;
+        }
+      }
+    }
   }
 }
 
