@@ -231,6 +231,7 @@ def main():
     opt = FusedAdamW(model, base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True,
                      max_grad_norm=1.0, warmup_steps=100, t_total=100000,
                      overlap_reduce=False if os.environ.get("BENCH_LAYER_HOOK", "1") == "0" else None)
+    opt.flag_sumsq = os.environ.get("BENCH_FLAG_SUMSQ", "1") != "0"
     batch = tuple(t.to(dev) for t in make_batch(args.batch, num_boxes=num_boxes, num_locs=num_locs, l2_normalize=l2n,
                                                 seed=1234 + rank))
     crit = torch.nn.CrossEntropyLoss()

@@ -54,6 +54,7 @@ _SIGS = {
     "vl_adamw": (c_int, [P, P, P, P, c_int64, P, P, P, c_int64, c_float, c_float, c_float, c_int64, c_int, c_float,
                          P, c_float, c_int, P, c_int64, c_int64, c_int64, P]),
     "vl_sumsq": (c_int, [P, c_int64, P, P]),
+    "vl_sumsq_flagged": (c_int, [P, c_int64, P, P, c_int64, c_int64, c_int64, P]),
 }
 
 

@@ -285,5 +285,9 @@ def adamw(param, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, seg_wd, beta1, beta
                                    flag_row_len, _stream()), "vl_adamw")
 
 
-def sumsq(x, out):
-    _lib.check(_lib.lib().vl_sumsq(_p(x), x.numel(), _p(out), _stream()), "vl_sumsq")
+def sumsq(x, out, row_flags=None, flag_begin=0, flag_rows=0, flag_row_len=0):
+    if row_flags is None:
+        _lib.check(_lib.lib().vl_sumsq(_p(x), x.numel(), _p(out), _stream()), "vl_sumsq")
+    else:
+        _lib.check(_lib.lib().vl_sumsq_flagged(_p(x), x.numel(), _p(out), _p(row_flags), flag_begin, flag_rows,
+                                               flag_row_len, _stream()), "vl_sumsq_flagged")

@@ -195,6 +195,7 @@ class FusedAdamW(object):
         # (needs one optimizer step per backward: pass overlap_reduce=False when accumulating gradients)
         self._pre, self._works, self._layer_plan = set(), [], None
         self.keep_reduced_grad = False
+        self.flag_sumsq = True
         if overlap_reduce is None:
             # also with one GPU: the layer gradients then reach the arena by one multi-tensor copy per layer on the
             # weight-gradient stream instead of ~90 autograd copies (views of the packed Q/K/V gradient) + one big
@@ -353,7 +354,8 @@ class FusedAdamW(object):
         if self.keep_reduced_grad:  # tests: the summed gradient and the 1/world factor the kernels apply to it
             self.last_reduced_grad, self.last_post = a.grad.clone(), post
         self._sumsq.zero_()
-        ops.sumsq(a.grad, self._sumsq)
+        # (table rows that never received a gradient are exact zeros: not read)
+        ops.sumsq(a.grad, self._sumsq, **(self._flag_args() if self.flag_sumsq else {}))
         # clip coefficient on the device: min(1, max_norm / (||g|| + 1e-6)) with ||g|| of the averaged gradient
         norm = self._sumsq.sqrt() * post
         torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0, out=self._scale)

@@ -218,6 +218,10 @@ int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64
              void* stream);
 /* out[0] += sum(x^2) over n floats (atomic; zero out[0] first). */
 int vl_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* same, not reading the rows of the flagged table range (vl_adamw's row_flags arguments) whose flag is 0: they never
+ * received a gradient and hold exact zeros */
+int vl_sumsq_flagged(const float* x, int64_t n, float* out, const uint8_t* row_flags, int64_t flag_begin,
+                     int64_t flag_rows, int64_t flag_row_len, void* stream);
 
 #ifdef __cplusplus
 }

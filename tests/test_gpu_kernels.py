@@ -445,6 +445,20 @@ def test_adamw_and_sumsq():
     out = torch.zeros(1, device=DEV)
     ops.sumsq(g, out)
     torch.testing.assert_close(out.double().cpu(), (g0 * g0).sum().view(1), rtol=1e-5, atol=1e-5)
+    # flagged form: a table range whose unflagged rows are exact zeros (and are not read)
+    rows, rl, beg = 37, 24, 40
+    x = _rand(beg + rows * rl + 19, seed=31)
+    flags = (torch.rand(rows, generator=torch.Generator().manual_seed(32)) < 0.4).to(torch.uint8).to(DEV)
+    tbl = x[beg:beg + rows * rl].view(rows, rl)
+    tbl[flags == 0] = 0
+    o1, o2 = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+    ops.sumsq(x, o1)
+    ops.sumsq(x, o2, row_flags=flags, flag_begin=beg, flag_rows=rows, flag_row_len=rl)
+    torch.testing.assert_close(o2, o1, rtol=1e-5, atol=1e-6)
+    tbl[flags == 0] = 7.0  # proves those rows are skipped
+    o3 = torch.zeros(1, device=DEV)
+    ops.sumsq(x, o3, row_flags=flags, flag_begin=beg, flag_rows=rows, flag_row_len=rl)
+    torch.testing.assert_close(o3, o1, rtol=1e-5, atol=1e-6)
 
 
 def test_adamw_untouched_row_fast_path_is_bit_identical():
