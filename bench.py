@@ -293,10 +293,12 @@ def main():
     def fwd_bwd():
         loss_, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, dev, "TASK15", batch, model, crit)
         loss_.backward()
+        opt.discard_grads()  # no optimizer step: drop the gradients instead of accumulating them over iterations
     n_extra = 0 if args.no_extras else max(3, args.steps // 2)
     fb_rate = None
     if n_extra:
-        opt.set_overlap(False)  # no optimizer step between these backward passes
+        if world > 1:
+            opt.set_overlap(False)  # forward+backward only: no gradient exchange either
         fwd_bwd()
         fb_rate = world * args.batch * n_extra / timed(fwd_bwd, n_extra)
         opt.zero_grad()

@@ -291,6 +291,18 @@ class FusedAdamW(object):
         if eng is not None:
             eng.pending_word_grad = None
 
+    def discard_grads(self):
+        """Forget the gradients of the last backward without zero-filling the arena: the next backward overwrites the
+        layer gradients (benchmarking forward+backward alone; everything else should use zero_grad())."""
+        for w in self._works:
+            w.wait()
+        self._works, self._pre = [], set()
+        for _, p, _, _ in self.groups:
+            p.grad = None
+        eng = getattr(self.model, "engine", None)
+        if eng is not None:
+            eng.pending_word_grad = None
+
     def _flag_args(self):
         if self.row_flags is None:
             return {}
