@@ -5,6 +5,24 @@ Mirrors of the reference's helpers, same names and argument meaning:
 * ``see_weight_rate_uc2(model)``                              -- :92-177 (% of pruned entries)
 * ``rewind_uc2(pre_weight, model_prefix)``                    -- :179-256 (theta_0 snapshot with ``_orig`` key renames)
 * ``pruning_model_custom(model, mask_dict, module)``          -- volta/train_task_sft.py:44-132 (apply mask_best.pt)
+* ``pruning_model_m3p`` / ``see_weight_rate_m3p`` / ``rewind_m3p`` / ``pruning_model_custom_m3p`` -- the M3P lists of
+  volta/train_task_prunning.py:258-307, :309-392, :394-435 and volta/train_task_sft.py:134-215 (12 x {attentions,
+  ffns, encoder_attn} + latent / original transforms + the pooler and pre-training heads; 73 of those 136 Linear
+  weights are on the fine-tuning path, the rest are parameter holders that never receive a gradient).
+
+Tie contract of the selection (the one place where "the same index set" is not defined by the reference): with
+equal |w| AT the k-th order statistic torch.topk's pick is implementation-defined -- its CPU kernel (introselect)
+picks arbitrary members, its device kernel (radix select + index-ordered gather) the lowest flat indices.
+``vl_imp_select`` prunes every entry strictly below the threshold value and, of the entries equal to it, the lowest
+flat indices until k is reached: identical to torch everywhere outside the tie group, identical count inside it
+(tests/golden/imp_sft.npz pins both with a planted straddling tie in every round).
+
+Scored weights (a reference quirk worth knowing, reproduced on request): from the second round on
+``prune.global_unstructured`` reads ``module.weight``, which under re-parametrisation is the plain attribute the
+last forward pre-hook left behind -- ``weight_orig * weight_mask`` as of the LAST FORWARD, i.e. before the epoch's
+final optimizer step.  ``snapshot_scored_weights`` takes that snapshot (the prune driver calls it right before the
+last ``opt.step()`` of an epoch) and ``pruning_model_*`` score it when given; without a snapshot the current
+``weight_orig * weight_mask`` is scored (one optimizer step fresher than the reference).
 
 The module list (73 Linear weights, 85 524 480 elements for full UC2) and its ``named_modules()`` order are the
 reference's.  The selection itself -- torch's ``prune.global_unstructured(L1Unstructured, amount)`` -- runs on the
@@ -34,30 +52,53 @@ def uc2_prunable_names(n_sublayers=24, embeddings=False, cls=False, task="TASK15
     return names
 
 
+def m3p_prunable_names(n_layers=12):
+    """The reference's M3P list (train_task_prunning.py:258-290), in its own order."""
+    names = []
+    for ii in range(n_layers):
+        names += ["bert.encoder.attentions.%d.%s" % (ii, s) for s in ("q_lin", "k_lin", "v_lin", "out_lin")]
+        names += ["bert.encoder.ffns.%d.lin1" % ii, "bert.encoder.ffns.%d.lin2" % ii]
+        names += ["bert.encoder.encoder_attn.%d.%s" % (ii, s) for s in ("q_lin", "k_lin", "v_lin", "out_lin")]
+    for ii in range(2):
+        names += ["bert.encoder.latent_transforms.%d.%s" % (ii, s) for s in ("x_to_mu", "x_to_logvar", "out_dense")]
+        names += ["bert.encoder.original_transforms.%d.%s" % (ii, s) for s in ("dense", "dense_mu")]
+    names += ["bert.encoder.pooled_layer.dense", "bert.encoder.seq_relationship", "bert.encoder.pooled_layer2.dense",
+              "bert.encoder.seq_relationship2", "bert.encoder.mrfr_dense", "bert.encoder.transformer_obj.dense"]
+    return names
+
+
 def _selected_modules(model, names):
+    """(name, module) in named_modules() order -- the concatenation order of the reference (the pooler of M3P is
+    registered twice, as bert.encoder.pooled_layer and bert.pooler: named_modules() yields the first name only)."""
     want = set(names)
-    return [(n, m) for n, m in model.named_modules() if n in want]  # named_modules() order, like the reference
+    return [(n, m) for n, m in model.named_modules() if n in want]
 
 
 def _n_sublayers(model):
     return len(model.bert.encoder.layer)
 
 
-def pruning_model_uc2(model, px, embeddings=False, global_pruning=True, cls=False, bias=False):
-    """One round of global L1 magnitude pruning: the ``round(px * n_remaining)`` smallest |weight| among the still
-    unmasked entries of the prunable modules get mask 0.  Returns the number of newly pruned entries."""
-    if not global_pruning or bias:
-        raise NotImplementedError("clg_vqa_amd: the reference runs global weight pruning only "
-                                  "(train_task_prunning.py:723-726: bias=False, global_pruning=True)")
-    mods = _selected_modules(model, uc2_prunable_names(_n_sublayers(model), embeddings, cls))
+def _current_weight(m):
+    """What ``module.weight`` holds right after a forward: weight_orig * weight_mask, or the plain parameter."""
+    if "weight_orig" in m._parameters:
+        return m._parameters["weight_orig"].detach() * m._buffers["weight_mask"]
+    return m.weight.detach()
+
+
+def snapshot_scored_weights(model, names):
+    """Clone of ``module.weight`` as the last forward pre-hook left it (call between the last forward of an epoch and
+    its optimizer step): the tensor the reference's next ``global_unstructured`` call scores."""
+    return {n: _current_weight(m).clone() for n, m in _selected_modules(model, names)}
+
+
+def _global_prune_round(model, names, px, scored=None):
+    mods = _selected_modules(model, names)
     ws, ms = [], []
-    for _, m in mods:
-        if "weight_orig" in m._parameters:
-            ws.append(m._parameters["weight_orig"].detach().reshape(-1))
-            ms.append(m._buffers["weight_mask"].reshape(-1))
-        else:
-            ws.append(m.weight.detach().reshape(-1))
-            ms.append(torch.ones_like(ws[-1]))
+    for n, m in mods:
+        w = scored[n] if scored is not None else (m._parameters["weight_orig"] if "weight_orig" in m._parameters
+                                                  else m.weight).detach()
+        ws.append(w.reshape(-1).to(torch.float32))
+        ms.append(m._buffers["weight_mask"].reshape(-1) if "weight_orig" in m._parameters else torch.ones_like(ws[-1]))
     w_flat, m_flat = torch.cat(ws), torch.cat(ms)
     n_remaining = int(m_flat.sum().item())  # once per epoch; every mask entry is exactly 0 or 1
     k = round(px * n_remaining)             # torch prune.py:_compute_nparams_toprune
@@ -77,9 +118,25 @@ def pruning_model_uc2(model, px, embeddings=False, global_pruning=True, cls=Fals
     return k
 
 
-def see_weight_rate_uc2(model, embedding=False, cls=False, bias=False):
+def pruning_model_uc2(model, px, embeddings=False, global_pruning=True, cls=False, bias=False, scored=None):
+    """One round of global L1 magnitude pruning: the ``round(px * n_remaining)`` smallest |weight| among the still
+    unmasked entries of the prunable modules get mask 0.  Returns the number of newly pruned entries."""
+    if not global_pruning or bias:
+        raise NotImplementedError("clg_vqa_amd: the reference runs global weight pruning only "
+                                  "(train_task_prunning.py:723-726: bias=False, global_pruning=True)")
+    return _global_prune_round(model, uc2_prunable_names(_n_sublayers(model), embeddings, cls), px, scored)
+
+
+def pruning_model_m3p(model, px, global_pruning=True, scored=None):
+    """train_task_prunning.py:258-307 with global_pruning=True (:726), on the M3P module list."""
+    if not global_pruning:
+        raise NotImplementedError("clg_vqa_amd: the reference runs global pruning only (train_task_prunning.py:726)")
+    return _global_prune_round(model, m3p_prunable_names(len(model.bert.encoder.attentions)), px, scored)
+
+
+def _zero_rate(model, names):
     total, zeros = 0.0, 0.0
-    for _, m in _selected_modules(model, uc2_prunable_names(_n_sublayers(model), embedding, cls)):
+    for _, m in _selected_modules(model, names):
         mask = m._buffers.get("weight_mask")
         if mask is None:
             total += m.weight.numel()
@@ -87,6 +144,16 @@ def see_weight_rate_uc2(model, embedding=False, cls=False, bias=False):
         total += float(mask.nelement())
         zeros += float(torch.sum(mask == 0))
     return 100 * zeros / total
+
+
+def see_weight_rate_uc2(model, embedding=False, cls=False, bias=False):
+    """train_task_prunning.py:92-177."""
+    return _zero_rate(model, uc2_prunable_names(_n_sublayers(model), embedding, cls))
+
+
+def see_weight_rate_m3p(model):
+    """train_task_prunning.py:309-392."""
+    return _zero_rate(model, m3p_prunable_names(len(model.bert.encoder.attentions)))
 
 
 def rewind_uc2(pre_weight, model="", embeddings=False, cls=False, bias=False, n_sublayers=24):
@@ -108,16 +175,31 @@ def rewind_uc2(pre_weight, model="", embeddings=False, cls=False, bias=False, n_
     return recover
 
 
-def pruning_model_custom(model, mask_dict, module="", embeddings=False, cls=False, bias=False):
-    """Install the masks of a ``mask_best.pt`` dict (keys ``<module>....weight_mask``) by module name."""
-    if bias:
-        raise NotImplementedError("clg_vqa_amd: bias masks are not used by the reference scripts (bias=False)")
-    names = uc2_prunable_names(_n_sublayers(model), embeddings, cls)
+def rewind_m3p(pre_weight, model="", n_layers=12):
+    """train_task_prunning.py:394-435: theta_0 snapshot -> ``*.weight_orig`` keys for the M3P list (only keys with
+    'bert.encoder' in them are kept, like the reference)."""
+    name_list = {model + n + ".weight" for n in m3p_prunable_names(n_layers)}
+    return {(k + "_orig" if k in name_list else k): v for k, v in pre_weight.items() if "bert.encoder" in k}
+
+
+def _install_masks(model, names, mask_dict, module):
     for n, m in _selected_modules(model, names):
         mask = mask_dict["%s%s.weight_mask" % (module, n)].to(m.weight.device, torch.float32)
         prune.CustomFromMask.apply(m, "weight", mask=mask)
     if hasattr(model, "mark_weights_dirty"):
         model.mark_weights_dirty()
+
+
+def pruning_model_custom(model, mask_dict, module="", embeddings=False, cls=False, bias=False):
+    """Install the masks of a ``mask_best.pt`` dict (keys ``<module>....weight_mask``) by module name."""
+    if bias:
+        raise NotImplementedError("clg_vqa_amd: bias masks are not used by the reference scripts (bias=False)")
+    _install_masks(model, uc2_prunable_names(_n_sublayers(model), embeddings, cls), mask_dict, module)
+
+
+def pruning_model_custom_m3p(model, mask_dict, module=""):
+    """train_task_sft.py:134-215."""
+    _install_masks(model, m3p_prunable_names(len(model.bert.encoder.attentions)), mask_dict, module)
 
 
 def premultiply_by_mask(model, mask_dict):

@@ -76,3 +76,50 @@ def ForwardModelsVal(config, task_cfg, device, task_id, batch, model, criterion)
     loss = loss.mean() * target.size(1)
     batch_score = compute_score_with_logits(vil_prediction, target).sum()
     return float(loss), float(batch_score), batch_size
+
+
+class _LabelSpace(object):
+    """Stand-in for ``dataloader.dataset`` where only ``label2ans`` is read (task_utils.py:839)."""
+
+    def __init__(self, label2ans):
+        self.label2ans = label2ans
+
+
+class _Loader(object):
+    def __init__(self, label2ans):
+        self.dataset = _LabelSpace(label2ans)
+
+
+def label_space(label2ans):
+    """A ``dataloader``-shaped holder of the answer vocabulary for ``EvaluatingModel`` (the reference reads
+    ``dataloader.dataset.label2ans[...]``; its GQA dataset loads the list from ``trainval_label2ans.pkl``)."""
+    return _Loader(list(label2ans))
+
+
+def EvaluatingModel(config, task_cfg, device, task_id, batch, model, dataloader, criterion, results, others):
+    """volta/volta/task_utils.py:716-841, the VL-classifier(-GQA) branches: forward without gradients, argmax ->
+    ``{"questionId": str(id), "prediction": label2ans[argmax]}`` appended to ``results`` (the format
+    scripts/GQA_score.py reads); returns ``(loss, score, batch_size, results, others)`` with loss = score = 0 for GQA
+    like the reference (:832-833).  ``batch`` is the eval tuple (features, spatials, image_mask, question, target,
+    input_mask, segment_ids, question_id, ixs[, distances])."""
+    batch = _to_device(batch, device)
+    features, spatials, image_mask, question, target, input_mask, segment_ids, question_id = batch[:8]
+    batch_size = features.size(0)
+    with torch.no_grad():
+        vil_prediction = model(question, features, spatials, task_id, segment_ids, input_mask, image_mask)[0]
+    ttype = task_cfg[task_id]["type"]
+    if ttype == "VL-classifier-GQA":
+        logits = torch.max(vil_prediction, 1)[1]
+        loss, batch_score = 0, 0
+        label2ans = dataloader.dataset.label2ans
+        for qid, lab in zip(question_id.tolist(), logits.tolist()):
+            results.append({"questionId": str(qid), "prediction": label2ans[lab]})
+    elif ttype == "VL-classifier":
+        logits = torch.max(vil_prediction, 1)[1]
+        loss, batch_score = 0, 0
+        label2ans = dataloader.dataset.label2ans
+        for qid, lab in zip(question_id.tolist(), logits.tolist()):
+            results.append({"question_id": qid, "answer": label2ans[lab]})
+    else:
+        raise ValueError("clg_vqa_amd.task_utils: unsupported task type %s" % ttype)
+    return float(loss), float(batch_score), batch_size, results, others

@@ -58,3 +58,23 @@ def uc2_cfg_dict(hidden=768, heads=12, inter=3072, n_layers=12, vocab=250002):
     for k in ("shared_sublayers", "single_ln_sublayers"):
         cfg[k] = list(range(n_sub))
     return cfg
+
+
+def check_imp_contract(w_flat, mask_before, mask_after, k, expect_tie_group=None):
+    """What global magnitude pruning defines without reference to an implementation (see clg_vqa_amd/sft.py):
+    exactly k newly pruned entries, every previously unmasked entry with |w| strictly below the threshold value T
+    pruned, none above T pruned; entries equal to T form the tie group, of which any k - (#below T) may be pruned.
+    Returns (T, tie group indices, pruned members of the tie group).  numpy arrays, fp32 values."""
+    w = np.abs(np.asarray(w_flat, dtype=np.float32) * np.asarray(mask_before, dtype=np.float32))
+    before = np.asarray(mask_before) == 1
+    after = np.asarray(mask_after) == 1
+    assert not (after & ~before).any(), "a pruned entry came back"
+    new = before & ~after
+    assert int(new.sum()) == int(k), (int(new.sum()), int(k))
+    T = np.partition(w[before], k - 1)[k - 1]  # k-th smallest remaining magnitude
+    assert new[before & (w < T)].all(), "an entry strictly below the threshold survived"
+    assert not new[before & (w > T)].any(), "an entry strictly above the threshold was pruned"
+    ties = np.nonzero(before & (w == T))[0]
+    if expect_tie_group is not None:
+        np.testing.assert_array_equal(ties, expect_tie_group)
+    return T, ties, ties[new[ties]]
