@@ -30,6 +30,8 @@ _SIGS = {
     "vl_ln_bwd_reduce2": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, c_int64, P]),
     "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
+    "vl_attn2_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
+    "vl_attn2_bwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_ln_fwd": (c_int, [P, P, P, c_int64, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64,
                           c_int64, c_float, c_float, c_uint64, P]),
     "vl_ln_bwd_ws_floats": (c_int64, [c_int64, c_int64]),

@@ -1,0 +1,489 @@
+// vl_attn2_fwd / vl_attn2_bwd: the V&L attention core over the single stream X = [text ; boxes] on the bf16 matrix
+// pipe (v_mfma_f32_16x16x32_bf16), reading the (hi, lo) bf16 split of Q/K/V that the QKV projection's epilogue writes.
+//
+// Reference: volta/volta/encoders.py:255-341 (BertGatedSelfAttention.forward): with UC2's has_tt = tv = vt = vv and
+// shared weights the four gated score blocks, the two concatenated softmaxes, the four dropouts and the four P.V
+// products are ONE multi-head attention over S = T + V tokens with the additive key mask [t_mask ; v_mask]
+// (encoders.py:978-995); M3P's MultiHeadAttention (volta/volta/m3p_transformer.py:152-212) is the same op with a -inf
+// key mask.  Queries at padded positions are still computed.
+//
+// Precision (DESIGN.md "Precision"): forward = 3-term split products x ~= hi + lo (16 significant bits per operand):
+// Q.K^T as Kh.Ql + Kl.Qh + Kh.Qh and P.V with P split in registers -- fp32-grade like the projections around it;
+// backward = single-pass bf16 on the hi halves, like every other backward product of the engine.
+//
+// One workgroup (4 waves) per (sample, head); K and V (forward) / Q, K, V, dO (backward) tiles live in LDS as
+// [row][64] bf16 with a 144-byte row pitch (conflict-free for ds_read_b128 operand reads and for the transposing
+// ds_read_b64_tr_b16 reads).  S <= 160: a query tile's whole key range lives in registers (plain softmax).
+//
+// Register-resident probabilities.  Scores are computed TRANSPOSED, S^T[key][query] = K.Q^T: the MFMA result layout
+// (lane: column = lane & 15, rows 4*(lane >> 4) + r) then gives a lane ONE query and 4 consecutive keys per key tile,
+// so the softmax reductions are in-lane plus two cross-lane steps, and the same registers ARE the B operand of the
+// next product contracting over keys (ctx^T = V^T.P^T forward, dQ^T = K^T.dS^T backward): P never goes through LDS.
+// The 8 k-slots of a lane's operand are keys {16t + 4g + e, 16(t+1) + 4g + e} (g = lane >> 4, e < 4), a permutation of
+// the 32 keys of a tile pair; the other operand (V^T / K^T) is gathered with transposing LDS reads using the same
+// permutation, so the contraction is unchanged.  The backward products that contract over QUERIES (dK, dV) use the
+// non-transposed layout the same way, in a second phase that owns key tiles (no cross-wave reduction, no atomics).
+//
+// Dropout on the probabilities: counter-based, one 32-bit hash per (query, key pair), regenerated in backward.
+#include "common.h"
+#include "../../include/vlhip.h"
+
+namespace {
+
+constexpr int DH = 64;
+constexpr int PITCH = 144;  // bytes per [row][64] bf16 LDS row
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+struct Attn2Args {
+  const bf16_raw* qkv_hi; const bf16_raw* qkv_lo; const float* addmask;
+  bf16_raw* ctx_hi; bf16_raw* ctx_lo; float* lse;
+  const bf16_raw* dctx; bf16_raw* dqkv;
+  int B, S, nh, H;   // H = nh * 64
+  int nq;            // queries per sample that are computed / carry a gradient (S, or 1: only the pooled row is live)
+  int ctx_rows;      // rows per sample of ctx / dctx (S, or 1 in the compact layout)
+  float scale, p_drop, inv_keep;
+  unsigned seed_lo, seed_hi, thr16;
+};
+
+__device__ __forceinline__ f32x4 mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ bf16x8 lds_frag(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+// 8 k-values (rows r0.., r1.. of the LDS image; 4 each) of column (lane & 15) of a 16-column block: see gemm.hip tr_frag
+__device__ __forceinline__ bf16x8 tr_frag2(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 zero_frag() {
+  const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+  return __builtin_bit_cast(bf16x8, z);
+}
+__device__ __forceinline__ bf16x8 pack8(const float* x) {
+  s16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (short)f32_to_bf16(x[i]);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void pack8_split(const float* x, bf16x8& hi, bf16x8& lo) {
+  s16x8 h, l;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    bf16_raw a, b;
+    split_bf16(x[i], a, b);
+    h[i] = (short)a; l[i] = (short)b;
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// 32 random bits per (row, key pair): two 16-bit uniform draws (low half = even key, high half = odd key)
+__device__ __forceinline__ unsigned hash32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned drop_bits(const Attn2Args& p, unsigned row, unsigned pair, unsigned pairs_per_row) {
+  return hash32(hash32((row * pairs_per_row + pair) * 0x9E3779B1u + p.seed_lo) ^ p.seed_hi);
+}
+__device__ __forceinline__ float keep_of(const Attn2Args& p, unsigned bits, int odd) {
+  const unsigned u = odd ? (bits >> 16) : (bits & 0xFFFFu);
+  return u >= p.thr16 ? p.inv_keep : 0.0f;
+}
+
+// stage rows [0, Spad) x 64 bf16 of one matrix into an LDS tile (zeros beyond `rows`); src row pitch ld elements
+__device__ __forceinline__ void stage16(unsigned char* dst, const bf16_raw* src, long ld, int rows, int Spad, int tid) {
+  for (int idx = tid; idx < Spad * 8; idx += 256) {
+    const int row = idx >> 3, c = idx & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < rows) v = *reinterpret_cast<const uint4*>(src + (long)row * ld + c * 8);
+    *reinterpret_cast<uint4*>(dst + row * PITCH + c * 16) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  constexpr int Spad = NT * 16, NP = (NT + 1) / 2;  // key-tile pairs
+  unsigned char* sKh = sm;
+  unsigned char* sKl = sKh + Spad * PITCH;
+  unsigned char* sVh = sKl + Spad * PITCH;
+  unsigned char* sVl = sVh + Spad * PITCH;
+  float* smask = reinterpret_cast<float*>(sVl + Spad * PITCH);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x - b * p.nh;
+  const int S = p.S;
+  const long ld = 3L * p.H;
+  const bf16_raw* bh = p.qkv_hi + (long)b * S * ld + h * DH;
+  const bf16_raw* bl = p.qkv_lo + (long)b * S * ld + h * DH;
+  stage16(sKh, bh + p.H, ld, S, Spad, tid);
+  stage16(sKl, bl + p.H, ld, S, Spad, tid);
+  stage16(sVh, bh + 2 * p.H, ld, S, Spad, tid);
+  stage16(sVl, bl + 2 * p.H, ld, S, Spad, tid);
+  for (int k = tid; k < Spad; k += 256) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
+  const int l15 = lane & 15, g = lane >> 4, qq = l15 >> 2, pp = lane & 3;
+  const int nqt = (p.nq + 15) >> 4;
+  __syncthreads();
+
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + l15;
+    // this lane's query row as the B operand of S^T = K.Q^T: Q[q][32 ks + 8 g ..]
+    bf16x8 qh[2], ql[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 vh = make_uint4(0u, 0u, 0u, 0u), vl = vh;
+      if (q < S) {
+        vh = *reinterpret_cast<const uint4*>(bh + (long)q * ld + 32 * ks + 8 * g);
+        vl = *reinterpret_cast<const uint4*>(bl + (long)q * ld + 32 * ks + 8 * g);
+      }
+      qh[ks] = __builtin_bit_cast(bf16x8, vh);
+      ql[ks] = __builtin_bit_cast(bf16x8, vl);
+    }
+    f32x4 sc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int off = (t * 16 + l15) * PITCH + 16 * g;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kh = lds_frag(sKh + off + 64 * ks), kl = lds_frag(sKl + off + 64 * ks);
+        sc[t] = mfma(kh, ql[ks], sc[t]);
+        sc[t] = mfma(kl, qh[ks], sc[t]);
+        sc[t] = mfma(kh, qh[ks], sc[t]);
+      }
+    }
+    // softmax over the keys of query q: this lane holds keys 16 t + 4 g + r
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const float4 mk = *reinterpret_cast<const float4*>(smask + 16 * t + 4 * g);
+      sc[t][0] = sc[t][0] * p.scale + mk.x; sc[t][1] = sc[t][1] * p.scale + mk.y;
+      sc[t][2] = sc[t][2] * p.scale + mk.z; sc[t][3] = sc[t][3] * p.scale + mk.w;
+      m = fmaxf(m, fmaxf(fmaxf(sc[t][0], sc[t][1]), fmaxf(sc[t][2], sc[t][3])));
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        sc[t][r] = __expf(sc[t][r] - m);
+        sum += sc[t][r];
+      }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (g == 0 && q < S) p.lse[((long)b * p.nh + h) * S + q] = m + __logf(sum);
+    const unsigned row = (unsigned)((b * p.nh + h) * S + q);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      float k0 = 1.f, k1 = 1.f, k2 = 1.f, k3 = 1.f;
+      if (p.p_drop > 0.f) {
+        const unsigned b0 = drop_bits(p, row, (unsigned)(8 * t + 2 * g), Spad / 2);
+        const unsigned b1 = drop_bits(p, row, (unsigned)(8 * t + 2 * g + 1), Spad / 2);
+        k0 = keep_of(p, b0, 0); k1 = keep_of(p, b0, 1); k2 = keep_of(p, b1, 0); k3 = keep_of(p, b1, 1);
+      }
+      sc[t][0] *= inv * k0; sc[t][1] *= inv * k1; sc[t][2] *= inv * k2; sc[t][3] *= inv * k3;
+    }
+    // ctx^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+      const int t0 = 2 * pr, t1 = 2 * pr + 1;
+      float pv[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pv[r] = sc[t0][r];
+        pv[4 + r] = t1 < NT ? sc[t1 < NT ? t1 : t0][r] : 0.f;
+      }
+      bf16x8 ph, pl;
+      pack8_split(pv, ph, pl);
+      const int r0 = (16 * t0 + 4 * g + qq) * PITCH + 8 * pp;
+      const int r1 = (16 * (t1 < NT ? t1 : t0) + 4 * g + qq) * PITCH + 8 * pp;  // (the slots of a missing tile hold p = 0)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 vh = tr_frag2(sVh + r0 + 32 * dt, sVh + r1 + 32 * dt);
+        const bf16x8 vl = tr_frag2(sVl + r0 + 32 * dt, sVl + r1 + 32 * dt);
+        o[dt] = mfma(vh, pl, o[dt]);
+        o[dt] = mfma(vl, ph, o[dt]);
+        o[dt] = mfma(vh, ph, o[dt]);
+      }
+    }
+    if (q < p.nq) {
+      const long orow = (long)b * p.ctx_rows + q;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        ushort4 hi, lo;
+        split_bf16(o[dt][0], hi.x, lo.x); split_bf16(o[dt][1], hi.y, lo.y);
+        split_bf16(o[dt][2], hi.z, lo.z); split_bf16(o[dt][3], hi.w, lo.w);
+        const long off = orow * p.H + h * DH + 16 * dt + 4 * g;
+        *reinterpret_cast<ushort4*>(p.ctx_hi + off) = hi;
+        *reinterpret_cast<ushort4*>(p.ctx_lo + off) = lo;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward.  dO = dctx (bf16).  With P = softmax, Pd = P * keep, dP = dO.V^T, delta = rowsum(Pd * dP) (= rowsum(dO * O)),
+//   dS = P * (keep * dP - delta) * scale;   dV = Pd^T dO;   dK = dS^T Q;   dQ = dS K.
+// Phase A (a wave owns query tiles, transposed layout): delta and dQ.  Phase B (a wave owns key tiles, plain layout,
+// scores recomputed): dK and dV accumulate in registers over the query tiles.
+// ---------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+  constexpr int Spad = NT * 16, NP = (NT + 1) / 2;
+  unsigned char* sQ = sm;
+  unsigned char* sK = sQ + Spad * PITCH;
+  unsigned char* sV = sK + Spad * PITCH;
+  unsigned char* sO = sV + Spad * PITCH;  // dO
+  float* smask = reinterpret_cast<float*>(sO + Spad * PITCH);
+  float* slse = smask + Spad;
+  float* sdelta = slse + Spad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / p.nh, h = blockIdx.x - b * p.nh;
+  const int S = p.S;
+  const long ld = 3L * p.H;
+  const bf16_raw* bh = p.qkv_hi + (long)b * S * ld + h * DH;
+  stage16(sQ, bh, ld, S, Spad, tid);
+  stage16(sK, bh + p.H, ld, S, Spad, tid);
+  stage16(sV, bh + 2 * p.H, ld, S, Spad, tid);
+  stage16(sO, p.dctx + (long)b * p.ctx_rows * p.H + h * DH, p.H, p.nq, Spad, tid);
+  for (int k = tid; k < Spad; k += 256) {
+    smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
+    slse[k] = k < S ? p.lse[((long)b * p.nh + h) * S + k] : INFINITY;  // +inf -> P = 0 for padded queries
+    sdelta[k] = 0.f;
+  }
+  const int l15 = lane & 15, g = lane >> 4, qq = l15 >> 2, pp = lane & 3;
+  const int nqt = (p.nq + 15) >> 4;      // query tiles that carry a gradient
+  const int nqt_all = (S + 15) >> 4;
+  const unsigned row0 = (unsigned)((b * p.nh + h) * S);
+  bf16_raw* dq_base = p.dqkv + (long)b * S * ld + h * DH;
+  __syncthreads();
+
+  // ---- phase A: delta and dQ (transposed layout: lane = one query, keys 16 t + 4 g + r) ------------------------
+  for (int qt = wave; qt < nqt_all; qt += 4) {
+    const int q = qt * 16 + l15;
+    if (qt >= nqt) {  // rows without a gradient: dQ = 0
+      if (q < S) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<ushort4*>(dq_base + (long)q * ld + 16 * dt + 4 * g) = make_ushort4(0, 0, 0, 0);
+      }
+      continue;
+    }
+    bf16x8 fq[2], fo[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      fq[ks] = lds_frag(sQ + q * PITCH + 16 * g + 64 * ks);
+      fo[ks] = lds_frag(sO + q * PITCH + 16 * g + 64 * ks);
+    }
+    const float lse_q = slse[q];
+    f32x4 pv[NT], kd[NT];  // P and keep * dP
+    float delta = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+      const int off = (t * 16 + l15) * PITCH + 16 * g;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s = mfma(lds_frag(sK + off + 64 * ks), fq[ks], s);
+        dp = mfma(lds_frag(sV + off + 64 * ks), fo[ks], dp);
+      }
+      const float4 mk = *reinterpret_cast<const float4*>(smask + 16 * t + 4 * g);
+      const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
+      float kp[4] = {1.f, 1.f, 1.f, 1.f};
+      if (p.p_drop > 0.f) {
+        const unsigned b0 = drop_bits(p, row0 + (unsigned)q, (unsigned)(8 * t + 2 * g), Spad / 2);
+        const unsigned b1 = drop_bits(p, row0 + (unsigned)q, (unsigned)(8 * t + 2 * g + 1), Spad / 2);
+        kp[0] = keep_of(p, b0, 0); kp[1] = keep_of(p, b0, 1); kp[2] = keep_of(p, b1, 0); kp[3] = keep_of(p, b1, 1);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pr = __expf(s[r] * p.scale + mkv[r] - lse_q);
+        const float x = kp[r] * dp[r];
+        delta += pr * x;
+        pv[t][r] = pr;
+        kd[t][r] = x;
+      }
+    }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+    if (g == 0) sdelta[q] = delta;
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+      const int t0 = 2 * pr, t1 = (2 * pr + 1 < NT) ? 2 * pr + 1 : 2 * pr;
+      const bool has1 = 2 * pr + 1 < NT;
+      float dsv[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dsv[r] = pv[t0][r] * (kd[t0][r] - delta) * p.scale;
+        dsv[4 + r] = has1 ? pv[t1][r] * (kd[t1][r] - delta) * p.scale : 0.f;
+      }
+      const bf16x8 dsb = pack8(dsv);
+      const int r0 = (16 * t0 + 4 * g + qq) * PITCH + 8 * pp;
+      const int r1 = (16 * t1 + 4 * g + qq) * PITCH + 8 * pp;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma(tr_frag2(sK + r0 + 32 * dt, sK + r1 + 32 * dt), dsb, o[dt]);
+    }
+    if (q < S) {
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        ushort4 v;
+        v.x = f32_to_bf16(o[dt][0]); v.y = f32_to_bf16(o[dt][1]); v.z = f32_to_bf16(o[dt][2]); v.w = f32_to_bf16(o[dt][3]);
+        *reinterpret_cast<ushort4*>(dq_base + (long)q * ld + 16 * dt + 4 * g) = v;
+      }
+    }
+  }
+  __syncthreads();  // sdelta complete
+
+  // ---- phase B: dK and dV (plain layout: lane = one key, queries 16 qt + 4 g + r) ------------------------------
+  const int nqp = (nqt + 1) >> 1;  // query-tile pairs
+  for (int kt = wave; kt < NT; kt += 4) {
+    const int key = kt * 16 + l15;
+    bf16x8 fk[2], fv[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      fk[ks] = lds_frag(sK + key * PITCH + 16 * g + 64 * ks);
+      fv[ks] = lds_frag(sV + key * PITCH + 16 * g + 64 * ks);
+    }
+    const float mk = smask[key];
+    f32x4 dK[4], dV[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int pq = 0; pq < nqp; ++pq) {
+      float pdv[8], dsv[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int qt = 2 * pq + half;
+        if (qt < nqt) {
+          f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
+          const int off = (qt * 16 + l15) * PITCH + 16 * g;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s = mfma(lds_frag(sQ + off + 64 * ks), fk[ks], s);
+            dp = mfma(lds_frag(sO + off + 64 * ks), fv[ks], dp);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qr = qt * 16 + 4 * g + r;
+            const float pr = __expf(s[r] * p.scale + mk - slse[qr]);
+            float kp = 1.f;
+            if (p.p_drop > 0.f) kp = keep_of(p, drop_bits(p, row0 + (unsigned)qr, (unsigned)(key >> 1), Spad / 2), key & 1);
+            pdv[4 * half + r] = pr * kp;
+            dsv[4 * half + r] = pr * (kp * dp[r] - sdelta[qr]) * p.scale;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { pdv[4 * half + r] = 0.f; dsv[4 * half + r] = 0.f; }
+        }
+      }
+      const bf16x8 bpd = pack8(pdv), bds = pack8(dsv);
+      const int qt1 = (2 * pq + 1 < nqt) ? 2 * pq + 1 : 2 * pq;  // (the slots of a missing tile hold zeros)
+      const int r0 = (32 * pq + 4 * g + qq) * PITCH + 8 * pp;
+      const int r1 = (16 * qt1 + 4 * g + qq) * PITCH + 8 * pp;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        dV[dt] = mfma(tr_frag2(sO + r0 + 32 * dt, sO + r1 + 32 * dt), bpd, dV[dt]);
+        dK[dt] = mfma(tr_frag2(sQ + r0 + 32 * dt, sQ + r1 + 32 * dt), bds, dK[dt]);
+      }
+    }
+    if (key < S) {
+      bf16_raw* out = p.dqkv + ((long)b * S + key) * ld + h * DH;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        ushort4 a, c;
+        a.x = f32_to_bf16(dK[dt][0]); a.y = f32_to_bf16(dK[dt][1]); a.z = f32_to_bf16(dK[dt][2]); a.w = f32_to_bf16(dK[dt][3]);
+        c.x = f32_to_bf16(dV[dt][0]); c.y = f32_to_bf16(dV[dt][1]); c.z = f32_to_bf16(dV[dt][2]); c.w = f32_to_bf16(dV[dt][3]);
+        *reinterpret_cast<ushort4*>(out + p.H + 16 * dt + 4 * g) = a;
+        *reinterpret_cast<ushort4*>(out + 2 * p.H + 16 * dt + 4 * g) = c;
+      }
+    }
+  }
+}
+
+inline size_t fwd_lds(int NT) { return (size_t)NT * 16 * (4 * PITCH + 4); }
+inline size_t bwd_lds(int NT) { return (size_t)NT * 16 * (4 * PITCH + 12); }
+
+template <int NT>
+int launch_fwd(const Attn2Args& a, hipStream_t s) {
+  const size_t lds = fwd_lds(NT);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return vl_set_error(-3, "vl_attn2_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((attn2_fwd_kernel<NT>), dim3(a.B * a.nh), dim3(256), lds, s, a);
+  VL_CHECK_LAUNCH("vl_attn2_fwd");
+  return 0;
+}
+template <int NT>
+int launch_bwd(const Attn2Args& a, hipStream_t s) {
+  const size_t lds = bwd_lds(NT);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_kernel<NT>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return vl_set_error(-3, "vl_attn2_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL((attn2_bwd_kernel<NT>), dim3(a.B * a.nh), dim3(256), lds, s, a);
+  VL_CHECK_LAUNCH("vl_attn2_bwd");
+  return 0;
+}
+
+int fill_common(const char* fn, Attn2Args& a, int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop,
+                uint64_t seed) {
+  VL_CHECK_ARG(dh == DH, "%s: head dim must be 64 (got %lld)", fn, (long long)dh);
+  VL_CHECK_ARG(S >= 1 && S <= 160, "%s: sequence length T+V must be in [1,160] (got %lld)", fn, (long long)S);
+  VL_CHECK_ARG(B >= 1 && nh >= 1 && B * nh < (1LL << 30) && B * nh * S < (1LL << 31), "%s: bad B=%lld nh=%lld", fn,
+               (long long)B, (long long)nh);
+  VL_CHECK_ARG(nq >= 1 && nq <= S, "%s: nq must be in [1, S] (got %lld)", fn, (long long)nq);
+  VL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: dropout p must be in [0,1)", fn);
+  a.B = (int)B; a.S = (int)S; a.nh = (int)nh; a.H = (int)(nh * DH); a.nq = (int)nq; a.ctx_rows = (int)nq;
+  a.scale = 1.0f / sqrtf((float)dh); a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop);
+  a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32) * 0x85ebca6bu + 0x27d4eb2fu;
+  a.thr16 = (unsigned)(p_drop * 65536.0f + 0.5f);
+  return 0;
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int vl_attn2_fwd(const void* qkv_hi, const void* qkv_lo, const float* addmask, void* ctx_hi, void* ctx_lo,
+                            float* lse, int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop,
+                            uint64_t seed, void* stream) {
+  Attn2Args a{};
+  if (int rc = fill_common("vl_attn2_fwd", a, B, S, nh, dh, nq, p_drop, seed)) return rc;
+  VL_CHECK_ARG(qkv_hi && qkv_lo && addmask && ctx_hi && ctx_lo && lse, "vl_attn2_fwd: null pointer");
+  VL_CHECK_ARG(al16(qkv_hi) && al16(qkv_lo) && al16(ctx_hi) && al16(ctx_lo), "vl_attn2_fwd: pointers must be 16-byte aligned");
+  a.qkv_hi = (const bf16_raw*)qkv_hi; a.qkv_lo = (const bf16_raw*)qkv_lo; a.addmask = addmask;
+  a.ctx_hi = (bf16_raw*)ctx_hi; a.ctx_lo = (bf16_raw*)ctx_lo; a.lse = lse;
+  hipStream_t s = (hipStream_t)stream;
+  if (S <= 64) return launch_fwd<4>(a, s);
+  if (S <= 80) return launch_fwd<5>(a, s);
+  if (S <= 128) return launch_fwd<8>(a, s);
+  return launch_fwd<10>(a, s);
+}
+
+extern "C" int vl_attn2_bwd(const void* qkv_hi, const float* addmask, const void* dctx16, const float* lse,
+                            void* dqkv16, int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop,
+                            uint64_t seed, void* stream) {
+  Attn2Args a{};
+  if (int rc = fill_common("vl_attn2_bwd", a, B, S, nh, dh, nq, p_drop, seed)) return rc;
+  VL_CHECK_ARG(qkv_hi && addmask && dctx16 && lse && dqkv16, "vl_attn2_bwd: null pointer");
+  VL_CHECK_ARG(al16(qkv_hi) && al16(dctx16) && al16(dqkv16), "vl_attn2_bwd: pointers must be 16-byte aligned");
+  a.qkv_hi = (const bf16_raw*)qkv_hi; a.addmask = addmask; a.dctx = (const bf16_raw*)dctx16;
+  a.lse = const_cast<float*>(lse); a.dqkv = (bf16_raw*)dqkv16;
+  hipStream_t s = (hipStream_t)stream;
+  if (S <= 64) return launch_bwd<4>(a, s);
+  if (S <= 80) return launch_bwd<5>(a, s);
+  if (S <= 128) return launch_bwd<8>(a, s);
+  return launch_bwd<10>(a, s);
+}

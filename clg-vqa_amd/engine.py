@@ -368,7 +368,10 @@ class EngineBase(object):
         # <= B*T touched rows sparsely (all-gather) instead of all-reducing the dense 768 MB table gradient
         self.defer_word_grad = False
         self.pending_word_grad = None
-        self.base_seed = 0x5EED
+        # counter-based dropout RNG: (base_seed, calls) identify every mask of the run.  base_seed follows torch's seed
+        # (--seed -> torch.manual_seed before the model is built), the pair is stored in checkpoints and restored by
+        # train_utils.resume, so a resumed run continues the mask sequence instead of replaying it
+        self.base_seed = (0x5EED ^ torch.initial_seed()) & 0xFFFFFFFF
         self.calls = 0
 
     def mark_dirty(self):

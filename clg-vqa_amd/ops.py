@@ -161,6 +161,16 @@ def attn_bwd(qkv32, addmask, ctx_hi, ctx_lo, dctx32, lse, dqkv16, B, S, nh, dh, 
                                       _p(dqkv16), B, S, nh, dh, float(p_drop), int(seed), _stream()), "vl_attn_bwd")
 
 
+def attn2_fwd(qkv_hi, qkv_lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed, nq=None):
+    _lib.check(_lib.lib().vl_attn2_fwd(_p(qkv_hi), _p(qkv_lo), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
+                                       S if nq is None else nq, float(p_drop), int(seed), _stream()), "vl_attn2_fwd")
+
+
+def attn2_bwd(qkv_hi, addmask, dctx16, lse, dqkv16, B, S, nh, dh, p_drop, seed, nq=None):
+    _lib.check(_lib.lib().vl_attn2_bwd(_p(qkv_hi), _p(addmask), _p(dctx16), _p(lse), _p(dqkv16), B, S, nh, dh,
+                                       S if nq is None else nq, float(p_drop), int(seed), _stream()), "vl_attn2_bwd")
+
+
 def ln_fwd(y, resid, addvec, gamma, beta, eps, out32, out_hi, out_lo, mean, rstd, M, H, group=None, out_stride=0,
            out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None):
     group = M if group is None else group

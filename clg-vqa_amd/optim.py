@@ -63,6 +63,14 @@ class FlatArena(object):
             p.data = view
         self.grad_views = [self.grad[off:off + p.numel()].view_as(p) for (_, p, _, _), off in zip(groups, offs)]
 
+    def broadcast_from_rank0(self, group=None):
+        """Every rank takes rank 0's parameters (apex DistributedDataParallel.__init__,
+        volta/apex/apex/parallel/distributed.py:253: ``flat_dist_call([p.data for p in module.parameters()],
+        dist.broadcast, (0,))``): replicas that were seeded differently, or loaded a different / late checkpoint, cannot
+        silently diverge.  One broadcast of the flat arena (the parameters are views of it)."""
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.broadcast(self.param, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+
     def gather_grads(self, pre=()):
         """Copy the autograd-produced gradients into the flat gradient arena (params without a grad -- e.g.
         M3P's never-used modules -- contribute zeros, like apex skipping ``grad is None``).  `pre`: indices whose
@@ -162,6 +170,8 @@ class FusedAdamW(object):
         self.model = model
         self.groups = reference_param_groups(params, base_lr, weight_decay)
         self.arena = FlatArena(self.groups, device)
+        self.reducer = reducer or GradReducer()
+        self.arena.broadcast_from_rank0(self.reducer.group)  # DDP start: rank 0's parameters everywhere
         n = self.arena.total
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=device)
@@ -172,7 +182,6 @@ class FusedAdamW(object):
         self.betas, self.eps, self.correct_bias = betas, eps, correct_bias
         self.max_grad_norm = max_grad_norm
         self.warmup_steps, self.t_total = warmup_steps, t_total
-        self.reducer = reducer or GradReducer()
         self.sched_step = 0  # scheduler.step() count (train_task.py:335)
         self.opt_step = 0
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)

@@ -87,16 +87,17 @@ def _current_weight(m):
 
 def snapshot_scored_weights(model, names):
     """Clone of ``module.weight`` as the last forward pre-hook left it (call between the last forward of an epoch and
-    its optimizer step): the tensor the reference's next ``global_unstructured`` call scores."""
-    return {n: _current_weight(m).clone() for n, m in _selected_modules(model, names)}
+    its optimizer step): the tensor the reference's next ``global_unstructured`` call scores.  Only re-parametrised
+    modules are snapshotted: before the first round ``module.weight`` is the parameter itself, always current."""
+    return {n: _current_weight(m).clone() for n, m in _selected_modules(model, names) if "weight_orig" in m._parameters}
 
 
 def _global_prune_round(model, names, px, scored=None):
     mods = _selected_modules(model, names)
     ws, ms = [], []
     for n, m in mods:
-        w = scored[n] if scored is not None else (m._parameters["weight_orig"] if "weight_orig" in m._parameters
-                                                  else m.weight).detach()
+        w = scored[n] if (scored is not None and n in scored) else (
+            m._parameters["weight_orig"] if "weight_orig" in m._parameters else m.weight).detach()
         ws.append(w.reshape(-1).to(torch.float32))
         ms.append(m._buffers["weight_mask"].reshape(-1) if "weight_orig" in m._parameters else torch.ones_like(ws[-1]))
     w_flat, m_flat = torch.cat(ws), torch.cat(ms)

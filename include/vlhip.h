@@ -102,6 +102,20 @@ int vl_attn_bwd(const float* qkv32, const float* addmask, const void* ctx_hi, co
                 const float* dctx32, const float* lse, void* dqkv16, int64_t B, int64_t S, int64_t nh, int64_t dh,
                 float p_drop, uint64_t seed, void* stream);
 
+/* The same op on the bf16 matrix pipe, fed by the (hi, lo) split of Q/K/V that the QKV projection writes with
+ * VL_EPI_SPLIT (no fp32 copy of the projection goes through HBM):
+ * qkv_hi / qkv_lo [B*S, 3*nh*64] bf16, columns [Q | K | V].  Forward: 3-term split products (fp32-grade, like the
+ * projections around it); ctx (hi, lo) and lse as above.  Backward: single-pass bf16 on the hi halves (like every
+ * other backward product): dctx16 bf16 -> dqkv16 bf16; delta = rowsum(P * dP) is computed in the kernel, so the saved
+ * ctx is not read.  Dropout: counter-based, regenerated in backward from (seed).
+ * nq = number of queries per sample that are live: S normally; nq < S ("only the pooled row of the last layer feeds
+ * the head", encoders.py:597-608) computes / differentiates queries [0, nq) only, with ctx / dctx in the COMPACT layout
+ * [B*nq, nh*64]; dqkv16 is always the full [B*S, 3*nh*64] matrix (dQ rows >= nq are written as zeros). */
+int vl_attn2_fwd(const void* qkv_hi, const void* qkv_lo, const float* addmask, void* ctx_hi, void* ctx_lo, float* lse,
+                 int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop, uint64_t seed, void* stream);
+int vl_attn2_bwd(const void* qkv_hi, const float* addmask, const void* dctx16, const float* lse, void* dqkv16,
+                 int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * (dropout +) residual + LayerNorm, forward and backward.
  * Replaces apex fused_layer_norm_cuda.forward_affine / backward_affine (apex/csrc/layer_norm_cuda.cpp:139-239,

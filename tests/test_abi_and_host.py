@@ -95,3 +95,48 @@ def test_m3p_full_config_census_on_meta_device():
     with_grad = sum(p.numel() for p in m.engine.param_list()) + m.bert.pooler.dense.weight.numel() + \
         m.bert.pooler.dense.bias.numel() + sum(p.numel() for p in m.clfs_dict.parameters())
     assert with_grad == 283638066  # parameters that receive gradients
+
+
+def test_warmup_linear_matches_transformers_schedule():
+    """WarmupLinearSchedule of pytorch_transformers (train_task.py:271-274) lives on in transformers as
+    get_linear_schedule_with_warmup (importable here): pins the schedule of FusedAdamW and of the oracle's restated
+    optimizer step, including the reference's quirk that the FIRST optimizer step runs at lr = 0 when warm-up > 0."""
+    from transformers.optimization import get_linear_schedule_with_warmup
+    from clg_vqa_amd.optim import warmup_linear
+    from oracle.adamw_oracle import warmup_linear as oracle_warmup
+    for warm, total in ((0, 10), (3, 20), (10, 100), (7, 7)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=1.0)
+        sched = get_linear_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total)
+        for step in range(total + 3):
+            lr = opt.param_groups[0]["lr"]  # the lr optimizer.step() number `step` runs at
+            assert abs(lr - warmup_linear(step, warm, total)) < 1e-12, (warm, total, step)
+            assert abs(lr - oracle_warmup(step, warm, total)) < 1e-12
+            opt.step()
+            sched.step()
+
+
+def test_resume_uses_the_weights_only_loader(tmp_path):
+    """resume() must not unpickle arbitrary objects.  A checkpoint of this package's format loads; a file
+    holding a pickled object (what the reference's .tar does with its tbLogger) is refused with a clear message."""
+    from clg_vqa_amd import train_utils
+
+    class Opt(object):
+        sched_step = 3
+
+        def state_dict(self):
+            return {"exp_avg": torch.zeros(2), "opt_step": 3, "sched_step": 3, "names": ["a"], "row_flags": None}
+
+        def load_state_dict(self, sd):
+            self.loaded = sd
+
+    lin = torch.nn.Linear(2, 2)
+    train_utils._ckpt(str(tmp_path), lin.state_dict(), Opt(), 7, 1, 0.5, dropout_rng=[11, 22])
+    o = Opt()
+    _, gs, ep, _, best = train_utils.resume(str(tmp_path / "pytorch_ckpt_latest.tar"), lin, o, None, None)
+    assert (gs, ep, best) == (7, 2, 0.5) and o.loaded["names"] == ["a"]
+
+    import argparse
+    torch.save({"model_state_dict": {}, "tb_logger": argparse.Namespace(x=1)}, str(tmp_path / "ref.tar"))
+    with pytest.raises(RuntimeError, match="weights-only"):
+        train_utils.resume(str(tmp_path / "ref.tar"), lin, o, None, None)

@@ -24,6 +24,13 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # DDP start: replicas seeded DIFFERENTLY end up bit-identical to rank 0 (apex distributed.py:253)
+    torch.manual_seed(1000 + rank)
+    l0 = torch.nn.Linear(9, 5)
+    a0 = FlatArena(reference_param_groups([("w", l0.weight), ("b", l0.bias)], 1e-3, 0.0), torch.device("cpu"))
+    before = a0.param.clone()
+    a0.broadcast_from_rank0()
+    q.put(("bcast", rank, before.tolist(), a0.param.tolist(), l0.weight.detach().reshape(-1).tolist()))
     torch.manual_seed(0)  # identical replicas
     lin = torch.nn.Linear(37, 11)
     ln = torch.nn.LayerNorm(11)
@@ -63,7 +70,12 @@ def test_flat_arena_allreduce_world2():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2 * world)]
+    got = [q.get(timeout=120) for _ in range(3 * world)]
+    bc = sorted([g for g in got if g[0] == "bcast"])
+    got = [g for g in got if g[0] != "bcast"]
+    assert bc[0][2] != bc[1][2]                      # the replicas really started from different parameters
+    assert bc[0][3] == bc[1][3] == bc[0][2]          # ... and both hold rank 0's afterwards, bit for bit
+    assert bc[1][4] == bc[0][2][:45]                 # the module's parameter is a view of the arena
     sparse = sorted([g for g in got if g[0] == "sparse"])
     res = sorted([g for g in got if g[0] != "sparse"])
     ref = torch.zeros(13, 4)

@@ -44,7 +44,8 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    config, model, batch = _model_and_batch(3, 4, 100 + rank)
+    # replicas are built from DIFFERENT seeds: FusedAdamW's rank-0 broadcast (apex distributed.py:253) aligns them
+    config, model, batch = _model_and_batch(3 + 10 * rank, 4, 100 + rank)
     opt = _one_step(config, model, batch)
     assert opt._layer_plan is not None and model.engine.stack.layer_done_hook is not None  # overlap is the default
     torch.save({"grad": (opt.last_reduced_grad * opt.last_post).cpu(), "param": opt.arena.param.cpu()},

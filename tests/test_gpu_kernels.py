@@ -545,3 +545,122 @@ def test_gemm_224_row_tiles(M, N, K):
         u_ref = (x.double() @ w.double().t() + bias.double()).float()
         torch.testing.assert_close(outs[5][0].float(), _gelu_grad(u_ref), rtol=2 ** -8, atol=1e-4)
         torch.testing.assert_close(outs[5][1].float() + outs[5][2].float(), _gelu(u_ref), rtol=1e-4, atol=1e-4)
+
+
+def _attn2_inputs(B, S, nh, seed, scale=1.5):
+    H = nh * 64
+    qkv = _rand(B * S, 3 * H, seed=seed, scale=scale)
+    hi, lo = _split(qkv)
+    return qkv, hi, lo
+
+
+@pytest.mark.parametrize("B,T,V", [(3, 20, 36), (2, 40, 36), (2, 20, 100), (2, 40, 100), (1, 13, 20), (1, 60, 100), (2, 1, 1),
+                                   (1, 30, 50)])
+def test_attention2_forward_backward(B, T, V):
+    """bf16-pipe attention: forward (3-term split) is fp32-grade against fp64 math on the same (hi + lo) inputs; the
+    backward (single-pass bf16) against autograd within bf16 operand rounding."""
+    S, nh = T + V, 12
+    H = nh * 64
+    qkv, hi, lo = _attn2_inputs(B, S, nh, 12)
+    m = torch.ones(B, S, device=DEV)
+    if T > 6:
+        m[0, T - 5:T] = 0  # padded text tokens in sample 0
+    addmask = ((1 - m) * -10000.0).reshape(-1).contiguous()
+    ctx_hi = torch.full((B * S, H), float("nan"), dtype=BF16, device=DEV)
+    ctx_lo = torch.full_like(ctx_hi, float("nan"))
+    lse = torch.empty(B * nh * S, device=DEV)
+    ops.attn2_fwd(hi, lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, 0.0, 1)
+    q16 = (hi.double() + lo.double())
+    qd = q16.clone().requires_grad_(True)
+    ref, lse_ref = _attn_ref(qd, addmask.double().view(B, S), B, S, nh)
+    got = ctx_hi.double() + ctx_lo.double()
+    err = (got - ref.detach()).abs().max().item()
+    assert err < 3e-5 * max(1.0, ref.abs().max().item()), err
+    torch.testing.assert_close(lse.double().view(B, nh, S), lse_ref.detach(), rtol=1e-5, atol=2e-4)
+    # backward: reference = autograd at the bf16-rounded operands the kernel reads (hi halves, bf16 dO)
+    dctx = _rand(B * S, H, seed=13)
+    d16 = dctx.to(BF16)
+    qh = hi.double().clone().requires_grad_(True)
+    ref_h, _ = _attn_ref(qh, addmask.double().view(B, S), B, S, nh)
+    ref_h.backward(d16.double())
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=BF16, device=DEV)
+    ops.attn2_bwd(hi, addmask, d16, lse, dqkv, B, S, nh, 64, 0.0, 1)
+    g = qh.grad
+    assert torch.isfinite(dqkv.float()).all()
+    rel = (dqkv.double() - g).norm().item() / g.norm().item()
+    err = (dqkv.double() - g).abs().max().item()
+    print("attn2 bwd B=%d S=%d: rel-L2 %.3e, max abs %.3e (grad max %.3e)" % (B, S, rel, err, g.abs().max().item()))
+    assert rel <= 1e-2 and err <= 3e-2 * g.abs().max().item()  # P / dS are rounded to bf16 inside (2^-9 relative each)
+
+
+def test_attention2_pooled_row_mode_equals_the_dense_run():
+    """nq = 1 (only query 0 of every sample is live): ctx row 0 bit-equal to the dense run; the gradient equals the
+    dense run fed with dO = 0 everywhere but row 0."""
+    B, S, nh = 3, 56, 12
+    H = nh * 64
+    qkv, hi, lo = _attn2_inputs(B, S, nh, 31)
+    addmask = torch.zeros(B * S, device=DEV)
+    addmask[S - 4:S] = -10000.0
+    ctx_hi, ctx_lo = torch.empty(B * S, H, dtype=BF16, device=DEV), torch.empty(B * S, H, dtype=BF16, device=DEV)
+    lse = torch.empty(B * nh * S, device=DEV)
+    ops.attn2_fwd(hi, lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, 0.1, 5)
+    c_hi, c_lo = torch.empty(B, H, dtype=BF16, device=DEV), torch.empty(B, H, dtype=BF16, device=DEV)
+    lse1 = torch.zeros(B * nh * S, device=DEV)
+    ops.attn2_fwd(hi, lo, addmask, c_hi, c_lo, lse1, B, S, nh, 64, 0.1, 5, nq=1)
+    assert torch.equal(c_hi, ctx_hi.view(B, S, H)[:, 0]) and torch.equal(c_lo, ctx_lo.view(B, S, H)[:, 0])
+    assert torch.equal(lse1.view(B, nh, S)[:, :, 0], lse.view(B, nh, S)[:, :, 0])
+    d0 = _rand(B, H, seed=32).to(BF16)
+    dfull = torch.zeros(B, S, H, dtype=BF16, device=DEV)
+    dfull[:, 0] = d0
+    g_dense = torch.empty(B * S, 3 * H, dtype=BF16, device=DEV)
+    ops.attn2_bwd(hi, addmask, dfull.view(B * S, H), lse, g_dense, B, S, nh, 64, 0.1, 5)
+    g_c = torch.full((B * S, 3 * H), float("nan"), dtype=BF16, device=DEV)
+    ops.attn2_bwd(hi, addmask, d0, lse1, g_c, B, S, nh, 64, 0.1, 5, nq=1)
+    assert torch.equal(g_c, g_dense)
+
+
+def test_attention2_dropout_is_consistent_between_forward_and_backward():
+    B, T, V, nh, p = 2, 20, 36, 4, 0.25
+    S, H = T + V, nh * 64
+    qkv, hi, lo = _attn2_inputs(B, S, nh, 14, scale=1.0)
+    addmask = torch.zeros(B * S, device=DEV)
+    ctx_hi = torch.empty(B * S, H, dtype=BF16, device=DEV)
+    ctx_lo = torch.empty_like(ctx_hi)
+    lse = torch.empty(B * nh * S, device=DEV)
+    q2 = qkv.clone().view(B, S, 3, nh, 64)
+    q2[:, :, 2] = 1.0  # V = 1: ctx = rowsum(P * keep)
+    h2, l2 = _split(q2.view(B * S, 3 * H).contiguous())
+    ops.attn2_fwd(h2, l2, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, p, 77)
+    rowsum = (ctx_hi.float() + ctx_lo.float()).view(B, S, nh, 64)[..., 0]
+    assert abs(rowsum.mean().item() - 1.0) < 0.05 and (rowsum - 1.0).abs().max().item() > 1e-3
+    c2h, c2l = torch.empty_like(ctx_hi), torch.empty_like(ctx_hi)
+    ops.attn2_fwd(h2, l2, addmask, c2h, c2l, lse, B, S, nh, 64, p, 77)
+    assert torch.equal(c2h, ctx_hi)
+    ops.attn2_fwd(h2, l2, addmask, c2h, c2l, lse, B, S, nh, 64, p, 78)
+    assert not torch.equal(c2h, ctx_hi)
+    # keep rate: V = 1 and uniform P (Q = 0) -> ctx = (#kept keys) / S / (1 - p)
+    z = torch.zeros(B * S, 3 * H, device=DEV).view(B, S, 3, nh, 64)
+    z[:, :, 2] = 1.0
+    zh, zl = _split(z.view(B * S, 3 * H).contiguous())
+    ops.attn2_fwd(zh, zl, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, p, 123)
+    kept = (ctx_hi.float() + ctx_lo.float()).view(B, S, nh, 64)[..., 0] * (1 - p)
+    assert abs(kept.mean().item() - (1 - p)) < 0.01  # B*S*nh*S = 25 088 Bernoulli draws: sigma 0.003
+    # backward consistency via a directional finite difference of f(qkv) = sum(ctx * w) at the hi-rounded point
+    base = hi.float()
+    bh, bl = _split(base)
+    ops.attn2_fwd(bh, bl, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, p, 77)
+    w = _rand(B * S, H, seed=15).to(BF16)
+    dqkv = torch.empty(B * S, 3 * H, dtype=BF16, device=DEV)
+    ops.attn2_bwd(bh, addmask, w, lse, dqkv, B, S, nh, 64, p, 77)
+    d = torch.sign(dqkv.float()) * (0.5 + torch.rand(B * S, 3 * H, generator=torch.Generator().manual_seed(16)).to(DEV))
+    eps = 4e-3
+
+    def f(x):
+        xh, xl = _split(x.contiguous())
+        h_, l_ = torch.empty_like(ctx_hi), torch.empty_like(ctx_hi)
+        ops.attn2_fwd(xh, xl, addmask, h_, l_, lse.clone(), B, S, nh, 64, p, 77)
+        return ((h_.double() + l_.double()) * w.double()).sum().item()
+
+    fd = (f(base + eps * d) - f(base - eps * d)) / (2 * eps)
+    an = (dqkv.double() * d.double()).sum().item()
+    assert abs(fd - an) <= 3e-2 * max(1.0, abs(fd)), (fd, an)

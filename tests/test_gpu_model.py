@@ -84,6 +84,46 @@ def test_wide_layer_matches_reference_fixture():
     print("wide fixture: worst gradient rel-L2 error %.3e at %s" % worst)
 
 
+def test_full_depth_matches_reference_fixture():
+    """The full-depth trunk -- 12 layers, H 768, 12 heads, I 3072 (48 GEMMs deep), bs 8, vocab 2000 -- against the
+    fixture produced by the REAL reference: logits within 1e-3, loss, score (non-zero in the fixture), every
+    gradient against the fixture's digest and against the oracle."""
+    from helpers import grad_digest
+    g = load_golden("uc2_deep.npz")
+    config = golden_config(g)
+    assert len(config.tt_attn_sublayers) == 12
+    model, oracle = _build(config, int(g["seed"]))
+    batch = golden_batch(g)
+    loss, score, logits = _run_native(model, batch)
+    err = np.abs(logits.cpu().numpy() - g["logits"]).max()
+    print("deep fixture (12 layers): max |logit err| = %.3e (logit std %.3f), loss %.4f vs %.4f, score %.2f" % (
+        err, float(g["logits"].std()), float(loss), float(g["loss"]), float(score)))
+    assert err <= LOGIT_TOL
+    assert abs(float(loss) - float(g["loss"])) <= 2e-4 * abs(float(g["loss"]))
+    assert float(score) == float(g["score"]) == 0.5
+    # gradients vs the reference's digests (first 256 elements + L2 norm of every tensor)
+    names = bytes(g["grad_names"]).decode().split("\n")
+    params = dict(model.named_parameters())
+    worst_d = (0.0, None)
+    for n in names:
+        ref = g["grad::" + n]
+        got = grad_digest(params[n].grad)
+        if n.endswith("attention_self.key.bias"):
+            continue
+        scale = max(ref[-1], 1e-12)
+        assert abs(got[-1] - ref[-1]) <= GRAD_REL_L2 * scale, (n, got[-1], ref[-1])
+        if params[n].numel() >= 256:
+            rel = np.linalg.norm(got[:256] - ref[:256]) / max(np.linalg.norm(ref[:256]), 1e-12 * scale)
+            worst_d = max(worst_d, (float(rel), n))
+    print("deep fixture: worst rel error of the 256-element gradient heads vs the reference %.3e at %s" % worst_d)
+    oracle.eval()
+    oracle.zero_grad()
+    oloss, _, _ = O.forward_train(oracle, batch)
+    oloss.backward()
+    worst = _compare_grads(model, {n: p.grad for n, p in oracle.named_parameters()})
+    print("deep fixture: worst per-tensor gradient rel-L2 error vs the oracle %.3e at %s" % worst)
+
+
 @pytest.mark.parametrize("n_layers,B,T,V", [(2, 8, 20, 36), (3, 4, 40, 36), (2, 2, 20, 100),
                                             (2, 1, 6, 4),      # one sample, 10 rows in all: every tile is ragged
                                             (1, 3, 7, 9),      # odd everything (S = 16)
@@ -139,6 +179,38 @@ def test_sft_masks_via_torch_prune_by_module_name():
         assert torch.all(g[masks[n] == 0] == 0), n
         r = omods[n].weight_orig.grad
         assert (g - r).norm().item() <= GRAD_REL_L2 * r.norm().item(), n
+
+
+def test_c5_sft_masks_with_100_boxes_together():
+    """BASELINE config c5's combination: SFT masks AND the 100-box stream (S = 120) in one run."""
+    from torch.nn.utils import prune
+    config = BertConfig.from_dict(uc2_cfg_dict(n_layers=2, vocab=500))
+    model, oracle = _build(config, seed=23)
+    names = O.uc2_prunable_names(n_sublayers=4)
+    gen = torch.Generator().manual_seed(4321)
+    mods, omods = dict(model.named_modules()), dict(oracle.named_modules())
+    masks = {}
+    for n in names:
+        masks[n] = (torch.rand(mods[n].weight.shape, generator=gen) < 0.59).float()
+        mods[n].weight.data.mul_(masks[n].cuda())
+        omods[n].weight.data.mul_(masks[n])
+        prune.CustomFromMask.apply(mods[n], "weight", mask=masks[n].cuda())
+        prune.CustomFromMask.apply(omods[n], "weight", mask=masks[n])
+    batch = make_batch(4, seq_len=20, num_boxes=100, vocab_size=500, seed=33)
+    loss, score, logits = _run_native(model, batch)
+    oracle.eval()
+    oracle.zero_grad()
+    oloss, _, ologits = O.forward_train(oracle, batch)
+    oloss.backward()
+    err = (logits.cpu() - ologits.detach()).abs().max().item()
+    print("c5 (SFT masks + 100 boxes, S=120): max |logit err| = %.3e" % err)
+    assert err <= LOGIT_TOL
+    assert abs(float(loss) - float(oloss)) <= 2e-4 * abs(float(oloss))
+    for n in names:
+        gr = mods[n].weight_orig.grad.cpu()
+        assert torch.all(gr[masks[n] == 0] == 0), n
+        r = omods[n].weight_orig.grad
+        assert (gr - r).norm().item() <= GRAD_REL_L2 * r.norm().item(), n
 
 
 def test_training_mode_dropout_runs_and_is_seeded():

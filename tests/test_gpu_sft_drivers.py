@@ -10,56 +10,100 @@ import yaml
 
 pytestmark = pytest.mark.gpu
 
-from helpers import TASK_CFG, load_golden, uc2_cfg_dict  # noqa: E402
+from helpers import TASK_CFG, check_imp_contract, load_golden, uc2_cfg_dict  # noqa: E402
 from clg_vqa_amd import ops, sft, train_task  # noqa: E402
 from clg_vqa_amd.config import BertConfig  # noqa: E402
 from clg_vqa_amd.encoders import BertForVLTasks  # noqa: E402
 
 
 def test_imp_select_matches_reference_fixture_three_rounds():
-    g = load_golden("imp_sft.npz")  # produced by the real prune.global_unstructured(L1Unstructured, 0.1)
+    """Fixture from the real prune.global_unstructured(L1Unstructured, 0.1) with a tie group planted AT the k-th order
+    statistic of every round.  Contract (clg_vqa_amd/sft.py): the pruned set is identical to torch's outside the tie
+    group, the COUNT inside it is identical, and vl_imp_select takes the lowest flat indices of the group (torch's CPU
+    top-k took arbitrary members, recorded in the fixture; round r+1 continues from torch's mask)."""
+    g = load_golden("imp_sft.npz")
     ws = [torch.from_numpy(g["w%d" % i]) for i in range(int(g["n"]))]
     w = torch.cat([x.reshape(-1) for x in ws]).cuda()
     mask = torch.ones_like(w)
     for r in range(3):
         k = round(0.1 * int(mask.sum().item()))
+        assert k == int(g["k_round%d" % r])
         new = torch.empty_like(mask)
         ops.imp_select(w, mask, new, k)
-        idx = np.sort(np.nonzero(new.cpu().numpy() == 0)[0])
-        np.testing.assert_array_equal(idx, g["pruned_idx_round%d" % r])
-        mask = new
+        T, ties, pruned_ties = check_imp_contract(w.cpu().numpy(), mask.cpu().numpy(), new.cpu().numpy(), k,
+                                                  g["tie_idx_round%d" % r])
+        ref_new = np.ones(w.numel(), dtype=np.float32)
+        ref_new[g["pruned_idx_round%d" % r]] = 0
+        outside = np.ones(w.numel(), dtype=bool)
+        outside[ties] = False
+        np.testing.assert_array_equal(new.cpu().numpy()[outside], ref_new[outside])  # identical outside the tie group
+        assert len(pruned_ties) == len(g["tie_pruned_round%d" % r])                  # identical count inside it
+        np.testing.assert_array_equal(pruned_ties, ties[:len(pruned_ties)])          # ... lowest flat indices first
+        mask = torch.from_numpy(ref_new).cuda()
 
 
-def test_imp_select_large_random_bit_exact_vs_torch_topk():
-    gen = torch.Generator().manual_seed(3)
-    n = 3_000_001
-    w = (torch.randn(n, generator=gen) * 0.02)
-    mask = (torch.rand(n, generator=gen) < 0.8).float()
-    k = round(0.1 * int(mask.sum().item()))
-    slc = mask == 1
-    sub = (w * mask)[slc].abs()
-    ref = mask.clone()
-    part = torch.ones_like(sub)
-    part[torch.topk(sub, k, largest=False).indices] = 0
-    ref[slc] = part
-    new = torch.empty(n, device="cuda")
-    ops.imp_select(w.cuda(), mask.cuda(), new, k)
-    assert torch.equal(new.cpu(), ref)
-    assert int((new.cpu() == 0).sum()) == int((mask == 0).sum()) + k
+def test_imp_select_tie_rule_is_torch_device_topk():
+    """Same straddling ties against torch.topk ON THE DEVICE (the path the reference itself takes: it prunes a model
+    that lives on the GPU): torch's device top-k gathers threshold ties in index order, so the masks are identical
+    bit for bit, ties included -- at the fixture's size (single-block radix select) and at 3 M elements (multi-block)."""
+    g = load_golden("imp_sft.npz")
+    w_small = torch.cat([torch.from_numpy(g["w%d" % i]).reshape(-1) for i in range(int(g["n"]))])
+    gen = torch.Generator().manual_seed(5)
+    w_big = torch.randn(3_000_000, generator=gen) * 0.02
+    kth = torch.kthvalue(w_big.abs(), 300_000).values
+    donors = torch.randperm(3_000_000, generator=gen)[:40]
+    w_big[donors] = kth * torch.where(torch.arange(40) % 2 == 0, 1.0, -1.0)  # 41 equal magnitudes around rank 300 000
+    for w, k in ((w_small, int(g["k_round0"])), (w_big, 300_000 + 20)):
+        wd = w.cuda()
+        mask = torch.ones_like(wd)
+        new = torch.empty_like(wd)
+        ops.imp_select(wd, mask, new, k)
+        ref = torch.ones_like(wd)
+        ref[torch.topk(wd.abs(), k, largest=False).indices] = 0
+        _, ties, pruned_ties = check_imp_contract(w.numpy(), mask.cpu().numpy(), new.cpu().numpy(), k)
+        assert 0 < len(pruned_ties) < len(ties)  # the group really straddles the boundary
+        assert torch.equal(new, ref)
 
 
-def test_imp_select_threshold_ties_lowest_index_first():
-    w = torch.tensor([0.5, 0.1, 0.3, 0.1, 0.1, 0.9, 0.1, 0.05] * 700, device="cuda")
-    mask = torch.ones_like(w)
-    k = 700 + 1000  # all 0.05s + 1000 of the 2800 values equal to 0.1
-    new = torch.empty_like(w)
-    ops.imp_select(w, mask, new, k)
-    pruned = torch.nonzero(new == 0).flatten().cpu()
-    assert pruned.numel() == k
-    vals = w.cpu()[pruned]
-    assert int((vals == 0.05).sum()) == 700 and int((vals == 0.1).sum()) == 1000
-    tie_idx = torch.nonzero(w.cpu() == 0.1).flatten()
-    assert torch.equal(torch.sort(pruned[vals == 0.1]).values, tie_idx[:1000])  # lowest flat indices first
+def test_imp_full_size_three_rounds_vs_torch_topk_on_the_host():
+    """The real size: the 73 prunable Linear weights of full UC2 (85 524 480 elements) through
+    sft.pruning_model_uc2 (module walk, concatenation order, vl_imp_select, CustomFromMask / mask update), three
+    rounds, against the reference's arithmetic -- torch.topk(largest=False) on the concatenated |weight * mask| of
+    the still unmasked entries (prune.py:514-534) -- computed on the box's CPU.  Compared under the tie contract:
+    identical outside a (possible) threshold tie group, identical count inside."""
+    config = BertConfig.from_dict(uc2_cfg_dict(vocab=1000))  # full depth / width; the vocabulary is not prunable
+    model = BertForVLTasks(config, TASK_CFG, ["TASK15"]).cuda()
+    names = sft.uc2_prunable_names(24)
+    mods = dict(model.named_modules())
+    assert len(names) == 73 and sum(mods[n].weight.numel() for n in names) == 85524480
+    w_flat = torch.cat([mods[n].weight.detach().reshape(-1) for n in names]).cpu()
+    ref_mask = torch.ones_like(w_flat)
+    for r in range(3):
+        k_gpu = sft.pruning_model_uc2(model, 0.1, global_pruning=True)
+        got = torch.cat([mods[n].weight_mask.reshape(-1) for n in names]).cpu()
+        slc = ref_mask == 1
+        sub = (w_flat * ref_mask)[slc].abs()
+        k = round(0.1 * sub.numel())
+        assert k == k_gpu
+        part = torch.ones_like(sub)
+        part[torch.topk(sub, k, largest=False).indices] = 0
+        new_ref = ref_mask.clone()
+        new_ref[slc] = part
+        T, ties, pruned_ties = check_imp_contract(w_flat.numpy(), ref_mask.numpy(), got.numpy(), k)
+        outside = np.ones(w_flat.numel(), dtype=bool)
+        outside[ties] = False
+        assert np.array_equal(got.numpy()[outside], new_ref.numpy()[outside])
+        assert int((got[ties] == 0).sum()) == int((new_ref[ties] == 0).sum())
+        print("round %d: k = %d, threshold %.9g, %d entries tie at the threshold, %d of them pruned; zero rate %.2f %%" % (
+            r, k, T, len(ties), len(pruned_ties), sft.see_weight_rate_uc2(model)))
+        # continue from the reference's mask so that every round is compared on identical inputs
+        ptr = 0
+        for n in names:
+            m = mods[n].weight_mask
+            m.copy_(new_ref[ptr:ptr + m.numel()].view_as(m))
+            ptr += m.numel()
+        ref_mask = new_ref
+    assert abs(sft.see_weight_rate_uc2(model) - 27.1) < 0.01
 
 
 def _write_cfgs(tmp_path, n_layers=1, vocab=300):

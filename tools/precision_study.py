@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Regenerates the precision table of DESIGN.md §2 on the CPU oracle (tools only: imports oracle/, never the product).
+
+Every nn.Linear of the oracle (trunk + head: the 48 + 4 GEMMs of a forward) -- and, with --attn, the two attention
+products -- is replaced by a product whose OPERANDS are rounded the way a candidate MFMA scheme would feed them, with
+fp32 accumulation (the CPU's fp32 dot product stands in for the MFMA accumulator):
+
+    fp32            reference
+    bf16 / fp16     one pass, both operands rounded to the format
+    bf16x3          x = hi + lo (two bf16 terms, 16 significant bits): hi*hi + hi*lo + lo*hi        (3 MFMA passes)
+    fp16x2_act      activations hi + lo (two fp16 terms, 22 bits), weights one fp16 term            (2 passes)
+    fp16x2_w        weights hi + lo, activations one fp16 term                                      (2 passes)
+    bf16x2_act / bf16x2_w   the same with bf16 terms                                                 (2 passes)
+    fp16x3          both operands as two fp16 terms, three products                                 (3 passes)
+
+Reported: max |logit error| against the fp32 run (north_star's bound is 1e-3) for the forward schemes, and the
+per-tensor relative L2 error of the gradients (median / max over the 215 tensors) for backward schemes (forward kept
+fp32-grade = bf16x3, the engine's choice).  `--trajectory N` additionally trains N optimizer steps with each backward
+scheme against the fp32 run (dropout 0) and prints the loss drift: the CPU rehearsal of tests/test_gpu_trajectory.py.
+
+    python tools/precision_study.py --layers 12 --batch 8            # the table of DESIGN.md §2 (a few minutes on 8 cores)
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from helpers import TASK_CFG, uc2_cfg_dict  # noqa: E402
+from oracle import adamw_oracle as A  # noqa: E402
+from oracle import uc2_oracle as O  # noqa: E402
+from clg_vqa_amd.config import BertConfig  # noqa: E402
+from clg_vqa_amd.synthetic import make_batch, seeded_state_dict  # noqa: E402
+
+
+def _terms(x, fmt, n):
+    """x ~= sum of n terms of format fmt (each exactly representable), as fp32 tensors."""
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    out, r = [], x
+    for _ in range(n):
+        t = r.to(dt).to(torch.float32)
+        out.append(t)
+        r = r - t
+    return out
+
+
+def qmm(a, b, scheme):
+    """a [.., M, K] @ b [.., K, N] with operands fed as `scheme` says; a = activations / left, b = weights / right."""
+    if scheme == "fp32":
+        return a @ b
+    if scheme in ("bf16", "fp16"):
+        return _terms(a, scheme, 1)[0] @ _terms(b, scheme, 1)[0]
+    fmt = scheme[:4]
+    if scheme.endswith("x3"):
+        ah, al = _terms(a, fmt, 2)
+        bh, bl = _terms(b, fmt, 2)
+        return al @ bh + ah @ bl + ah @ bh
+    if scheme.endswith("x2_act"):
+        ah, al = _terms(a, fmt, 2)
+        bh = _terms(b, fmt, 1)[0]
+        return al @ bh + ah @ bh
+    if scheme.endswith("x2_w"):
+        ah = _terms(a, fmt, 1)[0]
+        bh, bl = _terms(b, fmt, 2)
+        return ah @ bl + ah @ bh
+    raise ValueError(scheme)
+
+
+class QLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, fwd, bwd):
+        ctx.save_for_backward(x, w)
+        ctx.bwd = bwd
+        y = qmm(x.reshape(-1, x.shape[-1]), w.t(), fwd).reshape(*x.shape[:-1], w.shape[0])
+        return y if b is None else y + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        x2, dy2 = x.reshape(-1, x.shape[-1]), dy.reshape(-1, dy.shape[-1])
+        dx = qmm(dy2, w, ctx.bwd).reshape(x.shape)
+        dw = qmm(dy2.t(), x2, ctx.bwd)
+        return dx, dw, dy2.sum(0), None, None
+
+
+class Patched(object):
+    """Context: nn.Linear (and optionally torch.matmul of the attention core) run through qmm."""
+
+    def __init__(self, fwd, bwd="fp32", attn=None):
+        self.fwd, self.bwd, self.attn = fwd, bwd, attn
+
+    def __enter__(self):
+        self._lin, self._mm = torch.nn.functional.linear, torch.matmul
+        fwd, bwd = self.fwd, self.bwd
+        torch.nn.functional.linear = lambda x, w, b=None: QLinear.apply(x, w, b, fwd, bwd)
+        if self.attn:
+            attn = self.attn
+            torch.matmul = lambda a, b: qmm(a, b, attn)
+        return self
+
+    def __exit__(self, *exc):
+        torch.nn.functional.linear, torch.matmul = self._lin, self._mm
+
+
+def build(layers, vocab, seed, dropout0=False):
+    cfg = uc2_cfg_dict(n_layers=layers, vocab=vocab)
+    if dropout0:
+        cfg.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    config = BertConfig.from_dict(cfg)
+    model = O.OracleUC2ForVLTasks(config, TASK_CFG, ["TASK15"], dropout_prob=0.0 if dropout0 else 0.1)
+    model.load_state_dict(seeded_state_dict(model.state_dict(), seed=seed), strict=True)
+    return model
+
+
+def run(model, batch, fwd, bwd, attn=None, grads=True):
+    model.eval()
+    model.zero_grad()
+    with Patched(fwd, bwd, attn):
+        loss, _, logits = O.forward_train(model, batch)
+        if grads:
+            loss.backward()
+    g = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None} if grads else None
+    return logits.detach(), g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--vocab", type=int, default=2000)
+    ap.add_argument("--seeds", type=int, default=2)
+    ap.add_argument("--trajectory", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=8)
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    fwd_schemes = ["bf16", "fp16", "bf16x2_act", "bf16x2_w", "fp16x2_act", "fp16x2_w", "bf16x3", "fp16x3"]
+    print("forward schemes: %d layers, batch %d, %d seed(s); max |logit error| vs fp32 (logit std in brackets)" % (
+        args.layers, args.batch, args.seeds))
+    res = {s: [] for s in fwd_schemes + ["bf16x3+attn_bf16x3"]}
+    stds = []
+    for seed in range(args.seeds):
+        model = build(args.layers, args.vocab, 40 + seed)
+        batch = make_batch(args.batch, vocab_size=args.vocab, seed=500 + seed)
+        ref, _ = run(model, batch, "fp32", "fp32", grads=False)
+        stds.append(ref.std().item())
+        for s in fwd_schemes:
+            lg, _ = run(model, batch, s, "fp32", grads=False)
+            res[s].append((lg - ref).abs().max().item())
+        lg, _ = run(model, batch, "bf16x3", "fp32", attn="bf16x3", grads=False)
+        res["bf16x3+attn_bf16x3"].append((lg - ref).abs().max().item())
+    passes = {"bf16": 1, "fp16": 1, "bf16x3": 3, "fp16x3": 3, "bf16x3+attn_bf16x3": 3}
+    print("| scheme | MFMA passes | max abs logit error (worst seed) | fits 1e-3 |")
+    print("|---|---|---|---|")
+    for s, v in res.items():
+        print("| %s | %d | %.2e (logit std %.2f) | %s |" % (s, passes.get(s, 2), max(v), np.mean(stds),
+                                                            "yes (%.0fx margin)" % (1e-3 / max(v)) if max(v) < 1e-3 else "NO"))
+    # backward schemes (forward fixed at the engine's bf16x3)
+    print("\nbackward schemes (forward bf16x3): per-tensor gradient rel-L2 error vs the fp32 run, median / max")
+    model = build(args.layers, args.vocab, 40)
+    batch = make_batch(args.batch, vocab_size=args.vocab, seed=500)
+    _, gref = run(model, batch, "fp32", "fp32")
+    print("| backward operands | passes | median | max | worst tensor |")
+    print("|---|---|---|---|---|")
+    for s in ("bf16", "fp16", "bf16x2_act", "bf16x3"):
+        _, g = run(model, batch, "bf16x3", s, attn=("bf16" if s == "bf16" else None))
+        rel = {n: ((g[n] - gref[n]).double().norm() / gref[n].double().norm().clamp_min(1e-30)).item()
+               for n in gref if not n.endswith("attention_self.key.bias")}
+        worst = max(rel, key=rel.get)
+        print("| %s%s | %d | %.2e | %.2e | %s |" % (s, " (+ bf16 attention core)" if s == "bf16" else "", passes.get(s, 2),
+                                                    float(np.median(list(rel.values()))), rel[worst], worst))
+    if args.trajectory:
+        print("\ntrajectory: %d optimizer steps (dropout 0, lr 4e-5, wd 1e-4, clip 1.0, warm-up 2 of 20), 2 layers, batch 8"
+              % args.trajectory)
+        hp = dict(base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True, warmup_steps=2,
+                  t_total=20, max_grad_norm=1.0)
+        batches = [make_batch(8, vocab_size=args.vocab, seed=900 + i) for i in range(4)]
+        runs = {}
+        for name, (f, b) in {"fp32": ("fp32", "fp32"), "bf16x3 fwd / bf16 bwd": ("bf16x3", "bf16"),
+                             "bf16x3 fwd / fp32 bwd": ("bf16x3", "fp32")}.items():
+            m = build(2, args.vocab, 77, dropout0=True)
+            m.train()
+            opt = A.ReferenceAdamW(m.named_parameters(), **hp)
+            losses = []
+            for s in range(args.trajectory):
+                with Patched(f, b):
+                    loss, _, _ = O.forward_train(m, batches[s % 4])
+                    loss.backward()
+                opt.step()
+                losses.append(float(loss))
+            runs[name] = (losses, {n: p.detach().clone() for n, p in m.named_parameters()})
+        base = runs["fp32"][0]
+        for name, (losses, _) in runs.items():
+            print("%-24s losses %s   max rel drift vs fp32 %.2e" % (
+                name, " ".join("%.2f" % x for x in losses), max(abs(a - b) / abs(b) for a, b in zip(losses, base))))
+
+
+if __name__ == "__main__":
+    main()
