@@ -7,105 +7,118 @@
 
 One "step" = one full training step of BASELINE.json configs[1] on one synthetic batch already resident in HBM:
 forward (dropout on) + GQA loss with semantic prior + backward + gradient all-reduce (N > 1) + clip + AdamW +
-zero-grad.  Weak scaling: 256 samples per GPU.  Rank 0 prints ONE JSON line.
+zero-grad.  Weak scaling: 256 samples per GPU.  Rank 0 prints ONE JSON line.  `--workload c3|c4|c5` runs the other
+BASELINE configs through the same code (their lines are committed under profiles/, they are not the headline).
 
 Extra objects on the line:
   roofline      the dominant kernel (the 3-pass bf16 MFMA GEMM of the forward): algorithmic FLOP (2*M*N*K per launch,
-                NOT x3 for the split passes) / HIP-event-measured duration over the timed region, against the dense
-                bf16 MFMA peak (2.5 PFLOP/s); "mfma_issue_frac" = passes x that (what the matrix pipe really issues).
-  cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on the box's host cores on a
-                bounded sample: UC2 full config, micro-batch 32, fwd+bwd, N = 1 / rank 0 only.
+                NOT x3 for the split passes) / duration measured live with HIP events on the launch stream inside the
+                timed region (the native stack brackets every 5th GEMM launch with caller-owned events), against the
+                dense bf16 MFMA peak (2.5 PFLOP/s); "mfma_issue_frac" = passes x that; "mfma_busy_pmc" and "traffic" come
+                from the newest committed rocprofv3 PMC summary of the same command (profiles/r*_summary.json).
+  cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on the box's host cores on a bounded
+                sample: UC2 full config, micro-batch 32, median of 5 steps after 2 warm-ups, forward+backward
+                and full step (+ restated clip / AdamW / schedule), N = 1 / rank 0 only.
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-
-
-def uc2_full_cfg():
-    from helpers import uc2_cfg_dict
-    return uc2_cfg_dict()  # volta/config/uc2_base.json values: 12 layers, H 768, 12 heads, I 3072, vocab 250002
+GFLOP_PER_SAMPLE = {"c2": 29.241, "c3": 29.241, "c4": 63.72, "c5": 63.71}  # SURVEY 8(d), training = 3 x forward
 
 
 class GemmTimer(object):
-    """HIP-event pairs around launches of the dominant kernel, on the stream they are launched on.  Every STRIDE-th
-    launch of the timed region is bracketed (an event pair costs ~12 us of host time and a bubble on the stream; timing
-    all 84 GEMMs of a step made the step 4 % slower than it is).  84 launches per step and STRIDE = 5 are co-prime, so
-    over the timed steps every GEMM of the step is sampled equally often."""
+    """HIP-event pairs around GEMM launches of the native stack, on the stream they run on.  Every STRIDE-th launch of
+    the timed region is bracketed (an event pair is a small bubble on the stream; timing all 84 GEMMs of a step made the
+    step 4 % slower than it is).  84 launches per step and STRIDE = 5 are co-prime, so over the timed steps every GEMM
+    of the step is sampled equally often."""
     STRIDE = 5
 
-    def __init__(self):
-        self.records = []  # (passes, flops, ev0, ev1)
-        self.enabled = False
-        self.count = 0
-
-    def wrap(self, ops_mod):
-        inner = ops_mod.gemm_nt
-        timer = self
-
-        def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw):
-            if not timer.enabled:
-                return inner(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw)
-            timer.count += 1
-            if timer.count % timer.STRIDE:
-                return inner(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw)
+    def __init__(self, stack, capacity=512):
+        from clg_vqa_amd._lib import header_constants
+        c = header_constants()
+        self.HDR, self.PAIR = c["VL_PROF_HEADER"], c["VL_PROF_PAIR"]
+        self.stack, self.capacity = stack, capacity
+        self.events = []
+        self.block = np.zeros(self.HDR + self.PAIR * capacity, dtype=np.int64)
+        for i in range(capacity):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            inner(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, **kw)
-            e1.record()
-            opb = 2 * (2 if passes == 3 else 1)  # bytes per operand element: bf16 hi (+ lo)
-            nbytes = opb * (M * K + N * K) + sum((4 if k in ("resid", "out32") else 2) * M * N
-                                                 for k in ("resid", "out32", "out_hi", "out_lo", "aux16") if kw.get(k) is not None)
-            timer.records.append((passes, 2.0 * M * N * K, e0, e1, nbytes))
+            e0.record(); e1.record()  # materialise the hipEvent_t handles
+            self.events.append((e0, e1))
+            self.block[self.HDR + self.PAIR * i] = e0.cuda_event
+            self.block[self.HDR + self.PAIR * i + 1] = e1.cuda_event
+        self.block[0], self.block[1] = self.STRIDE, capacity
 
-        ops_mod.gemm_nt = gemm_nt
+    def start(self):
+        self.block[2] = self.block[3] = 0
+        self.stack.prof = self.block
+
+    def stop(self):
+        self.stack.prof = None
 
     def summary(self):
         out = {}
-        for passes in (1, 3):
-            recs = [r for r in self.records if r[0] == passes]
-            if recs:
-                ms = sum(r[2].elapsed_time(r[3]) for r in recs)
-                out[passes] = dict(launches=len(recs), flops=sum(r[1] for r in recs), ms=ms,
-                                   bytes_per_launch=sum(r[4] for r in recs) / len(recs))
+        used = int(self.block[3])
+        for i in range(used):
+            tag, flops = int(self.block[self.HDR + self.PAIR * i + 2]), float(self.block[self.HDR + self.PAIR * i + 3])
+            ms = self.events[i][0].elapsed_time(self.events[i][1])
+            r = out.setdefault(tag // 16, dict(launches=0, flops=0.0, ms=0.0))
+            r["launches"] += 1
+            r["flops"] += flops
+            r["ms"] += ms
         return out
 
 
-def pmc_traffic_per_launch(prefix="gemm3_kernel<3,"):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/r*_summary.json,
-    produced by tools/profile_summary.py from separate rocprofv3 --pmc passes; FETCH_SIZE doubled for gfx950)."""
+def pmc_summary():
+    """Newest committed PMC summary (profiles/r*_summary.json; tools/profile_summary.py; separate rocprofv3 --pmc
+    passes, FETCH_SIZE doubled for gfx950): HBM bytes and MFMA-busy fraction per launch of the dominant kernel."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_summary.json")))
     if not files:
-        return None
+        return None, None, None
     try:
         pm = json.load(open(files[-1])).get("pmc", {})
-        tot, n = 0.0, 0
+        tot, n, busy, nb = 0.0, 0, 0.0, 0
         for k, v in pm.items():
-            if k.startswith(prefix):
+            if k.startswith("gemm3_kernel<3,"):
                 tot += (v["hbm_read_MB_per_launch"] + v["hbm_write_MB_per_launch"]) * 1e6 * v["launches"]
                 n += v["launches"]
-        return round(tot / n) if n else None
+                if v.get("mfma_busy_frac") is not None:
+                    busy += v["mfma_busy_frac"] * v["launches"]
+                    nb += v["launches"]
+        return (round(tot / n) if n else None), (round(busy / nb, 4) if nb else None), os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None, None
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """Oracle fwd+bwd on the host cores: UC2 full config, micro-batch 32."""
-    from helpers import TASK_CFG
+def cpu_model_string():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(seconds_budget=40.0):
+    """Oracle on the host cores: UC2 full config, micro-batch 32, median of 5 steps after 2 warm-ups, both
+    forward+backward and the full step (clip + AdamW + schedule restated in oracle/adamw_oracle.py)."""
+    from oracle import adamw_oracle as A
     from oracle import uc2_oracle as O
-    from clg_vqa_amd.config import BertConfig
+    from clg_vqa_amd.config import GQA_TASK_CFG, BertConfig, uc2_base_config
     from clg_vqa_amd.synthetic import make_batch
     cores = os.cpu_count() or 1
     try:
@@ -115,34 +128,45 @@ def cpu_baseline(seconds_budget=25.0):
     cores = min(cores, 16)  # a one-GPU box owns a 16-core share of the host; more threads only oversubscribe it
     torch.set_num_threads(cores)
     print("[bench] cpu_baseline: building the oracle (UC2 full config) on %d host threads" % cores, file=sys.stderr, flush=True)
-    config = BertConfig.from_dict(uc2_full_cfg())
+    config = BertConfig.from_dict(uc2_base_config())
     torch.manual_seed(0)
-    model = O.OracleUC2ForVLTasks(config, TASK_CFG, ["TASK15"])
+    model = O.OracleUC2ForVLTasks(config, GQA_TASK_CFG, ["TASK15"])
     for m in model.modules():
         if isinstance(m, (torch.nn.Linear, torch.nn.Embedding)):
             m.weight.data.normal_(0.0, 0.02)
     model.train()
     mb = 32
     batch = make_batch(mb, seed=99)
-    times = []
+    opt = A.ReferenceAdamW(model.named_parameters(), base_lr=4e-5, weight_decay=1e-4, warmup_steps=100, t_total=100000)
     t_start = time.time()
-    for i in range(4):
-        t0 = time.time()
-        model.zero_grad()
-        loss, _, _ = O.forward_train(model, batch)
-        loss.backward()
-        dt = time.time() - t0
-        print("[bench] cpu_baseline: step %d took %.2f s" % (i, dt), file=sys.stderr, flush=True)
-        if i > 0:
-            times.append(dt)
-        if time.time() - t_start > seconds_budget and len(times) >= 2:
-            break
-    times.sort()
-    med = times[len(times) // 2]
-    return dict(value=mb / med, unit="samples/s", cores=cores, kind="port",
-                sample="oracle (CPU restatement of volta BertForVLTasks, fp32 eager torch) UC2 full config, "
-                       "micro-batch 32, T=20 V=36, fwd+bwd with dropout, median of %d steps after 1 warm-up"
-                       % len(times))
+
+    def run(full, n_warm, n_timed):
+        times = []
+        for i in range(n_warm + n_timed):
+            t0 = time.time()
+            loss, _, _ = O.forward_train(model, batch)
+            loss.backward()
+            if full:
+                opt.step()
+            else:
+                model.zero_grad()
+            dt = time.time() - t0
+            print("[bench] cpu_baseline: %s step %d took %.2f s" % ("full" if full else "fwd+bwd", i, dt), file=sys.stderr, flush=True)
+            if i >= n_warm:
+                times.append(dt)
+            if time.time() - t_start > seconds_budget and len(times) >= 3:
+                break
+        times.sort()
+        return times[len(times) // 2], len(times)
+
+    fb, n_fb = run(False, 2, 5)
+    full, n_full = run(True, 1, 5)  # (the model is warm; one more warm-up for the optimizer state allocation)
+    return dict(value=mb / full, unit="samples/s", cores=cores, kind="port", cpu=cpu_model_string(),
+                fwd_bwd_samples_per_s=mb / fb,
+                sample="oracle (CPU restatement of volta BertForVLTasks, fp32 eager torch) UC2 full config, micro-batch 32, "
+                       "T=20 V=36, dropout on: value = full step (fwd+loss+bwd+clip+AdamW+schedule, median of %d steps after "
+                       "warm-up), fwd_bwd_samples_per_s = forward+backward only (median of %d steps after 2 warm-ups)"
+                       % (n_full, n_fb))
 
 
 def main():
@@ -167,6 +191,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     local_rank = local_rank % max(1, torch.cuda.device_count())  # gloo rehearsal: several ranks on one GPU
     if world > 1:
+        # RCCL over the xGMI mesh of one node: one process per GPU; dmabuf IPC (the host driver
+        # supports no legacy IPC); every GPU has a direct link to each of the 7 others, so RCCL's default ring/tree
+        # channel search already spreads the 12 per-layer all-reduces over all links -- no topology file is needed
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         if args.backend == "nccl":
@@ -176,56 +203,44 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    from helpers import TASK_CFG
-    from clg_vqa_amd import _lib, ops, task_utils
-    from clg_vqa_amd.config import BertConfig
+    from clg_vqa_amd import _lib, sft, task_utils
+    from clg_vqa_amd.config import GQA_TASK_CFG as TASK_CFG
+    from clg_vqa_amd.config import BertConfig, M3PConfig, m3p_base_config, uc2_base_config
     from clg_vqa_amd.encoders import BertForVLTasks
     from clg_vqa_amd.optim import FusedAdamW
     from clg_vqa_amd.synthetic import make_batch
 
-    timer = GemmTimer()
-    timer.wrap(ops)
-
     for kv in filter(None, os.environ.get("VL_DEBUG", "").split(",")):  # tuning knobs, e.g. VL_DEBUG=7:0,8:1
         k, v = kv.split(":")
         _lib.lib().vl_debug_set(int(k), int(v))
-    if os.environ.get("VL_LN_BLOCKS"):
-        _lib.lib().vl_ln_debug_blocks(int(os.environ["VL_LN_BLOCKS"]))
     num_boxes, num_locs, l2n = 36, 7, False
     if args.workload in ("c3", "c5"):
         args.sft = True
     if args.workload == "c5":
         num_boxes, args.batch = 100, (128 if args.batch == 256 else args.batch)
-    torch.manual_seed(1234)  # identical replicas on every rank (apex DDP broadcasts from rank 0 instead)
+    # replicas are built from the same seed; FusedAdamW additionally broadcasts rank 0's parameters (apex DDP start)
+    torch.manual_seed(1234)
     if args.workload == "c4":
-        from clg_vqa_amd.config import M3PConfig
         from clg_vqa_amd.m3p import M3PForVLTasks
         num_boxes, num_locs, l2n = 100, 5, True
-        config = M3PConfig.from_dict(dict(n_heads=12, emb_dim=768, n_layers=12, n_words=250002, vocab_size=250002,
-                                          hidden_size=768, pooler_size=768, clf_hidden_size=1536, num_locs=5,
-                                          image_embeddings="m3p", model="roberta", fusion_method="text",
-                                          norm_embeddings=True))  # volta/config/m3p_base.json
+        config = M3PConfig.from_dict(dict(m3p_base_config(), n_heads=12, emb_dim=768, n_layers=12))
         model = M3PForVLTasks(config, TASK_CFG, ["TASK15"]).to(dev)
     else:
-        config = BertConfig.from_dict(uc2_full_cfg())
+        config = BertConfig.from_dict(uc2_base_config())
         model = BertForVLTasks(config, TASK_CFG, ["TASK15"]).to(dev)
+    masked_elems = 0
     if args.sft:
         from torch.nn.utils import prune
-        sys.path.insert(0, ROOT)
-        from oracle.uc2_oracle import uc2_prunable_names
         gen = torch.Generator(device="cpu").manual_seed(4321)
         mods = dict(model.named_modules())
-        for n in uc2_prunable_names():
+        for n in sft.uc2_prunable_names():
             w = mods[n].weight
             mask = (torch.rand(w.shape, generator=gen) < 0.59).float().to(dev)
             w.data.mul_(mask)
             prune.CustomFromMask.apply(mods[n], "weight", mask=mask)
-    if os.environ.get("BENCH_PAIR_REDUCE", "1") == "0":
-        model.engine.stack.pair_reduce = False
-    if os.environ.get("BENCH_EARLY_JOIN", "0") == "1":
-        model.engine.stack.early_join = True
-    if os.environ.get("BENCH_GROUP_DW", "0") == "1":  # A/B: one grouped weight-gradient launch per layer
-        model.engine.stack.group_dw = True
+            masked_elems += w.numel()
+    if os.environ.get("BENCH_NO_OVERLAP", "0") == "1":  # A/B: weight-gradient work on the main stream
+        model.engine.stack.overlap_dw = False
     model.train()
     # reference hyper-parameters: experiments/zero_shot/uc2/xgqa/train.dtu.sh:20-28
     opt = FusedAdamW(model, base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True,
@@ -235,6 +250,7 @@ def main():
     batch = tuple(t.to(dev) for t in make_batch(args.batch, num_boxes=num_boxes, num_locs=num_locs, l2_normalize=l2n,
                                                 seed=1234 + rank))
     crit = torch.nn.CrossEntropyLoss()
+    timer = GemmTimer(model.engine.stack) if os.environ.get("BENCH_NO_GEMM_TIMER", "0") != "1" else None
 
     host = [0.0, 0.0, 0.0]  # host-side enqueue seconds (forward, backward, optimizer) -- diagnostics only
 
@@ -256,7 +272,8 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = os.environ.get("BENCH_NO_GEMM_TIMER", "0") != "1"
+    if timer is not None:
+        timer.start()
     host[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -266,7 +283,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    if timer is not None:
+        timer.stop()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -335,41 +353,48 @@ def main():
 
     if rank == 0:
         value = world * args.batch * args.steps / elapsed
-        gs = timer.summary()
+        gs = timer.summary() if timer is not None else {}
         roof = None
         if 3 in gs:
+            traffic, busy, src = pmc_summary()
             ach = gs[3]["flops"] / (gs[3]["ms"] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="gemm3_kernel<3,*> (forward GEMMs, 3-pass split bf16 MFMA, 8-wave ping-pong)", achieved=round(ach, 2),
-                        peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                        traffic=pmc_traffic_per_launch(), algorithmic_bytes_per_launch=round(gs[3]["bytes_per_launch"]), mfma_passes=3, mfma_issue_frac=round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
-                        launches=gs[3]["launches"], avg_launch_us=round(1e3 * gs[3]["ms"] / gs[3]["launches"], 2))
+            roof = dict(bound="mfma", kernel="gemm3_kernel<3,*> (forward GEMMs, 3-pass split bf16 MFMA, 8-wave ping-pong)",
+                        achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        traffic=traffic, mfma_passes=3, mfma_issue_frac=round(3 * ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                        mfma_busy_pmc=busy, pmc_source=src, launches=gs[3]["launches"],
+                        avg_launch_us=round(1e3 * gs[3]["ms"] / gs[3]["launches"], 2),
+                        algorithmic_flop_per_launch=round(gs[3]["flops"] / gs[3]["launches"]))
             if 1 in gs:
                 a1 = gs[1]["flops"] / (gs[1]["ms"] * 1e-3) / 1e12
                 roof["backward_gemm"] = dict(kernel="gemm3_kernel<1,*> (backward dX GEMMs, bf16 MFMA, 8-wave ping-pong)", achieved=round(a1, 2),
                                              frac=round(a1 / MFMA_BF16_PEAK_TFLOPS, 4), launches=gs[1]["launches"],
                                              avg_launch_us=round(1e3 * gs[1]["ms"] / gs[1]["launches"], 2))
+        seq = 20 + num_boxes
         line = {
             "metric": "VQA train samples/sec (UC2, 36 boxes, seq56, bs256)" if args.workload in ("c2", "c3") else
                       "VQA train samples/sec (%s, %d boxes, seq%d, bs%d) [not the headline config]" % (
-                          "M3P" if args.workload == "c4" else "UC2", num_boxes, 20 + num_boxes, args.batch),
+                          "M3P" if args.workload == "c4" else "UC2", num_boxes, seq, args.batch),
             "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "UC2 full config (12 layers, H768, 12 heads, I3072, vocab 250002), GQA 1842 labels, "
-                                   "T=20 + V=36 (S=56), bs %d per GPU, %s fine-tune with_prior, dropout 0.1, "
+            "config": {"workload": "%s full config (12 layers, H768, 12 heads, I3072, vocab 250002), GQA 1842 labels, "
+                                   "T=20 + V=%d (S=%d), bs %d per GPU, %s fine-tune with_prior, dropout 0.1, "
                                    "full step = fwd+loss+bwd+allreduce+clip+AdamW+zero_grad" % (
-                                       args.batch, "SFT-masked" if args.sft else "dense"),
-                       "baseline_config": args.workload, "global_batch": world * args.batch, "seq_len": 20 + num_boxes, "parallelism": "dp%d" % world,
-                       "precision": "forward GEMMs 3-pass split bf16 MFMA (fp32-grade, logits within 1e-3); attention "
-                                    "core fp32 MFMA; backward GEMMs bf16 MFMA; fp32 residual stream / LN / optimizer",
-                       "algorithmic_tflop_per_step": round(29.241e-3 * world * args.batch, 3), "final_loss": final_loss},
+                                       "M3P" if args.workload == "c4" else "UC2", num_boxes, seq, args.batch,
+                                       "SFT-masked (73 masks, %d elements, fp32 {0,1} layout of the reference)" % masked_elems
+                                       if args.sft else "dense"),
+                       "baseline_config": args.workload, "global_batch": world * args.batch, "seq_len": seq, "parallelism": "dp%d" % world,
+                       "precision": "forward GEMMs + attention 3-pass split bf16 MFMA (fp32-grade, logits within 1e-3); "
+                                    "backward GEMMs + attention bf16 MFMA; fp32 residual stream / LN / optimizer",
+                       "algorithmic_tflop_per_step": round(GFLOP_PER_SAMPLE[args.workload] * 1e-3 * world * args.batch, 3),
+                       "final_loss": final_loss},
             "roofline": roof,
         }
-        gflop_per_sample = {"c2": 29.241, "c3": 29.241, "c4": 63.72, "c5": 63.71}[args.workload]
-        line["step_tflops"] = round(gflop_per_sample * 1e-3 * world * args.batch / (elapsed / args.steps), 2)
+        line["step_tflops"] = round(GFLOP_PER_SAMPLE[args.workload] * 1e-3 * world * args.batch / (elapsed / args.steps), 2)
         line["extras"] = {"fwd_bwd_only_samples_per_s": None if fb_rate is None else round(fb_rate, 1),
                           "h2d_inclusive_samples_per_s": None if h2d_rate is None else round(h2d_rate, 1),
-                          "reference_semantics_global256_samples_per_s": None if strong_rate is None else round(strong_rate, 1)}
+                          "reference_semantics_global256_samples_per_s": None if strong_rate is None else round(strong_rate, 1),
+                          "host_enqueue_ms_per_step": round(1e3 * sum(host) / args.steps, 2)}
         print("[bench] gpu part done: %.1f samples/s, %.2f ms/step" % (value, 1e3 * elapsed / args.steps), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             del model, opt

@@ -27,9 +27,16 @@ _SIGS = {
     "vl_gemm_tn_splitk_to": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, c_int64, c_int, P]),
     "vl_ln_debug_blocks": (c_int, [c_int]),
     "vl_ln_bwd_reduce": (c_int, [P, c_int64, c_int64, P, P, P, P]),
-    "vl_ln_bwd_reduce2": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, c_int64, P]),
+    "vl_ln_bwd_reduce2": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, c_int64, c_int, P]),
+    "vl_stack_desc_len": (c_int64, [c_int64]),
+    "vl_stack_fwd": (c_int, [P, c_int64, c_int64, P]),
+    "vl_stack_bwd": (c_int, [P, c_int64, c_int64, P, P]),
     "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
+    "vl_blocked_elems": (c_int64, [c_int64, c_int64]),
+    "vl_transpose_blocked": (c_int, [P, c_int64, c_int64, P]),
+    "vl_colsum_finalize": (c_int, [P, c_int64, c_int64, P, c_int64, c_int, P]),
+    "vl_dw_grouped": (c_int, [P, c_int64, c_int64, c_int, P]),
     "vl_attn2_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn2_bwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_ln_fwd": (c_int, [P, P, P, c_int64, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64,
@@ -37,6 +44,7 @@ _SIGS = {
     "vl_ln_bwd_ws_floats": (c_int64, [c_int64, c_int64]),
     "vl_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64,
                           c_float, c_float, c_uint64, P]),
+    "vl_memset_zero": (c_int, [P, c_int64, P]),
     "vl_mask_mul": (c_int, [P, P, P, c_int64, P]),
     "vl_weight_prep": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "vl_imp_ws_bytes": (c_int64, [c_int64]),
@@ -65,6 +73,19 @@ def header_symbols():
     with open(HEADER_PATH) as f:
         text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
     return sorted(set(re.findall(r"\b(vl_[a-z0-9_]+)\s*\(", text)))
+
+
+def header_constants():
+    """{name: value} of the `NAME = value` enumerators and `#define NAME value` integer constants of include/vlhip.h
+    (descriptor field indices of vl_stack_*): the header is the single source of truth for the binding."""
+    with open(HEADER_PATH) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    out = {}
+    for name, val in re.findall(r"\b(VL_[A-Z0-9_]+)\s*=\s*(-?\d+)", text):
+        out[name] = int(val)
+    for name, val in re.findall(r"#define\s+(VL_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|-?\d+)(?:ll)?\b", text):
+        out[name] = int(val, 0)
+    return out
 
 
 _lib = None

@@ -101,6 +101,43 @@ class M3PConfig(_ConfigBase):
     _defaults = _M3P_DEFAULTS
 
 
+def uc2_base_config(hidden=768, heads=12, inter=3072, n_layers=12, vocab=250002):
+    """The values of the reference's volta/config/uc2_base.json (the file itself stays in the reference tree), with a
+    configurable width / depth / vocabulary for tests and benchmarks."""
+    n_sub = 2 * n_layers
+    cfg = dict(attention_probs_dropout_prob=0.1, hidden_act="gelu", hidden_dropout_prob=0.1, hidden_size=hidden,
+               initializer_range=0.02, intermediate_size=inter, max_position_embeddings=514, num_attention_heads=heads,
+               pooler_size=hidden, type_vocab_size=2, vocab_size=vocab, pad_token_id=1, num_locs=7,
+               add_global_imgfeat=None, image_embeddings="uc2", model="roberta", v_attention_probs_dropout_prob=0.1,
+               v_hidden_act="gelu", v_hidden_dropout_prob=0.1, v_feature_size=2048, v_hidden_size=hidden,
+               v_initializer_range=0.02, v_pooler_size=1024, v_num_attention_heads=heads, v_intermediate_size=inter,
+               layer_norm_eps=1e-5, fusion_method="text", clf_hidden_size=hidden)
+    for k in ("tt_attn_sublayers", "tv_attn_sublayers", "vt_attn_sublayers", "vv_attn_sublayers"):
+        cfg[k] = list(range(0, n_sub, 2))
+    for k in ("t_ff_sublayers", "v_ff_sublayers"):
+        cfg[k] = list(range(1, n_sub, 2))
+    for k in ("shared_sublayers", "single_ln_sublayers"):
+        cfg[k] = list(range(n_sub))
+    return cfg
+
+
+def m3p_base_config(vocab=250002):
+    """The values of the reference's volta/config/m3p_base.json."""
+    return dict(attention_probs_dropout_prob=0.1, hidden_act="gelu", hidden_dropout_prob=0.1, hidden_size=768,
+                initializer_range=0.02, intermediate_size=3072, max_position_embeddings=514, n_heads=12, pooler_size=768,
+                type_vocab_size=1, vocab_size=vocab, n_words=vocab, pad_token_id=1, num_locs=5, image_embeddings="m3p",
+                model="roberta", v_attention_probs_dropout_prob=0.1, v_hidden_act="gelu", v_hidden_dropout_prob=0.1,
+                v_feature_size=2048, v_hidden_size=768, v_initializer_range=0.02, v_pooler_size=768,
+                v_num_attention_heads=12, v_intermediate_size=3072, norm_embeddings=True, fusion_method="text", itm_dim=1,
+                clf_hidden_size=1536)
+
+
+# the GQA entry (TASK15) of the reference's task YAMLs (volta/config_tasks/iglue_trainval_tasks_boxes36.dtu.yml), the
+# keys the hot path reads
+GQA_TASK_CFG = {"TASK15": {"type": "VL-classifier-GQA", "num_labels": 1842, "process": "normal", "semantic_lambda": 10,
+                           "loss": "CrossEntropyLoss"}}
+
+
 class TaskCfg(dict):
     """Attribute-style dict standing in for ``easydict.EasyDict`` (absent from the image)."""
 

@@ -1,0 +1,393 @@
+// Weight-gradient path: dW = dY^T X for the six Linear weights of a transformer layer (autograd of nn.Linear,
+// volta/volta/encoders.py:229-246 Q/K/V, :411-414 out-proj, :496-501 FFN1, :553-556 FFN2), with the SFT mask product
+// grad(weight_orig) = grad(weight) * weight_mask (train_task_sft.py:128-132; torch prune.py:20-31) and gradient
+// accumulation in the epilogue.
+//
+// The reduction dimension of these products is the B*S batch rows (14 336 at c2), which is the SLOW dimension of the
+// row-major activations.  Instead of gathering k-strided fragments (the TN kernel of gemm.hip), the operands are first
+// re-laid "K-major in blocks of 64 rows":
+//
+//      XT[mb][n][mi] = X[64*mb + mi][n]        (bf16; rows past M are ZERO, so K-tiles are always full)
+//
+// by vl_transpose_blocked (one launch for all eight operands of a layer, HBM-bound, on the weight-gradient stream; it
+// also leaves the per-block column sums of dY = the bias gradients' partial sums).  In that image the 64 k-values of an
+// output row are one contiguous 128-byte line, i.e. exactly the LDS row of the 8-wave ping-pong NT kernel (gemm.hip):
+// dW becomes an NT product with a K loop of B*S/64 tiles, accumulated in registers over the WHOLE K range -- no split-K
+// slabs, no reduce pass -- and written once, straight into the optimizer's gradient arena.  vl_dw_grouped runs all the
+// products of a layer as ONE launch (108 tiles of 256 x 256 at H = 768, I = 3072): it deliberately fills only part of
+// the chip, the rest stays with the backward critical path on the main stream.
+#include "common.h"
+#include "../../include/vlhip.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+constexpr int MAXT = 8;
+
+// ---------------------------------------------------------------------------------------------------------------
+// blocked transpose (+ column-sum partials)
+// ---------------------------------------------------------------------------------------------------------------
+struct TrEntry { const bf16_raw* src; long ld; int N; bf16_raw* dst; float* colsum; int unit0; };
+struct TrArgs { TrEntry e[MAXT]; int n; int M; int mblocks; int total_units; };
+
+constexpr int TP = 144;  // LDS row pitch (bytes) of the 64 x 64 tile: conflict-free transposing reads (attention2.hip)
+
+__global__ __launch_bounds__(256) void transpose_blocked_kernel(TrArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char tile[64 * TP];
+  __shared__ float cs[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, c16 = lane & 15;
+  for (int u = blockIdx.x; u < a.total_units; u += gridDim.x) {
+    int ei = 0;
+#pragma unroll
+    for (int i = 1; i < MAXT; ++i)
+      if (i < a.n && u >= a.e[i].unit0) ei = i;
+    const TrEntry& e = a.e[ei];
+    const int local = u - e.unit0;
+    const int nblocks = e.N >> 6;
+    const int mb = local / nblocks, nb = local - mb * nblocks;
+    // load: thread -> rows (tid >> 3) and (tid >> 3) + 32, 16-byte chunk tid & 7
+    const int r0 = tid >> 3, ch = tid & 7;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = r0 + 32 * i;
+      const long grow = (long)mb * 64 + r;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (grow < a.M) v = *reinterpret_cast<const uint4*>(e.src + grow * e.ld + nb * 64 + ch * 8);
+      *reinterpret_cast<uint4*>(tile + r * TP + ch * 16) = v;
+      if (e.colsum) {
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          s[2 * t] += __uint_as_float(w[t] << 16);
+          s[2 * t + 1] += __uint_as_float(w[t] & 0xFFFF0000u);
+        }
+      }
+    }
+    if (e.colsum) {  // rows of one chunk live in lanes with equal (lane & 7): fixed-order tree, then the 4 waves in order
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        s[t] += __shfl_xor(s[t], 8, 64);
+        s[t] += __shfl_xor(s[t], 16, 64);
+        s[t] += __shfl_xor(s[t], 32, 64);
+      }
+      if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) cs[wave][lane * 8 + t] = s[t];
+      }
+    }
+    __syncthreads();
+    if (e.colsum && tid < 64)
+      e.colsum[(long)mb * e.N + nb * 64 + tid] = (cs[0][tid] + cs[1][tid]) + (cs[2][tid] + cs[3][tid]);
+    // transposing reads: wave w takes columns [16 w, 16 w + 16); lane (c16, g) receives rows 8 g .. 8 g + 7 (+ 32 half)
+    bf16_raw* dst = e.dst + ((long)mb * e.N + nb * 64 + wave * 16 + c16) * 64;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const unsigned char* p0 = tile + (32 * half + 8 * g + qq) * TP + (16 * wave + 4 * pp) * 2;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * TP));
+      const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      *reinterpret_cast<s16x8*>(dst + 32 * half + 8 * g) = v;
+    }
+    __syncthreads();  // the tile is rewritten by the next unit
+  }
+}
+
+// out_t[c] (+)= sum_blk partial[blk][t * seg + c] for up to 4 destination segments of equal length `seg`
+struct CsArgs { const float* partial; int nblk; int N; int seg; float* out[4]; int accumulate; };
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(CsArgs a) {
+  __shared__ float red[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int n = blockIdx.x * 16 + tx;
+  float s = 0.f;
+  if (n < a.N)
+    for (int b = ty; b < a.nblk; b += 16) s += a.partial[(long)b * a.N + n];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < a.N) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) t += red[j][tx];
+    const int seg = n / a.seg;
+    float* o = a.out[seg] + (n - seg * a.seg);
+    *o = a.accumulate ? *o + t : t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// grouped NT ping-pong kernel on blocked-transposed operands (structure, hazards and swizzle: gemm.hip gemm3_kernel,
+// configuration 256 x 256, one bf16 pass)
+// ---------------------------------------------------------------------------------------------------------------
+struct DwProb {
+  const bf16_raw* a; const bf16_raw* b;  // AT [kt][a_rows][64] at this problem's first row, BT [kt][b_rows][64]
+  long ka, kb;                           // elements between consecutive K-tiles (rows_total * 64)
+  float* out; const float* mask; long ldo;
+  int M, N;                              // output rows (dY columns of this problem) x columns (X columns)
+  int tile0, tiles_n;
+};
+struct DwArgs { DwProb p[MAXT]; int nprob; int nk; int total_tiles; int accumulate; };
+
+__device__ __forceinline__ int swz3(int row) {
+  return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 4) ^ (row >> 2)) & 1) << 2);
+}
+
+__global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
+  constexpr int WC = 4;                        // wave grid 2 (M) x 4 (N)
+  constexpr int MI = 4, NJ = 2;                // 16 x 16 MFMA tiles per quadrant
+  constexpr int AH = 128, BH = 128;            // rows per half-tile
+  constexpr int OFF_A1 = AH * 128, OFF_B0 = 2 * AH * 128, OFF_B1 = OFF_B0 + BH * 128, STAGE = OFF_B1 + BH * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC;
+  const bool late = wave >= 4;
+
+  const int nwg = ga.total_tiles;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < MAXT; ++i)
+    if (i < ga.nprob && swz >= ga.p[i].tile0) pi = i;
+  const DwProb& P = ga.p[pi];
+  const int lt = swz - P.tile0;
+  const int tm = lt / P.tiles_n, tn = lt - tm * P.tiles_n;
+  const int row0 = tm * 256, col0 = tn * 256;
+  const int nk = ga.nk;
+
+  const bf16_raw* src[4][2];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool isB = x >= 2;
+      const int r = 8 * (wave + 8 * j) + (lane >> 3);
+      const int lc = (lane & 7) ^ swz3(r);
+      int g = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + r;
+      const int lim = (isB ? P.N : P.M) - 1;
+      g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
+      src[x][j] = (isB ? P.b : P.a) + (long)g * 64 + lc * 8;
+    }
+  const long kstep[2] = {P.ka, P.kb};
+  constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
+#define DW_ISSUE(x, kt)                                                                                          \
+  do {                                                                                                           \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][0] + (long)(kt) * kstep[(x) >> 1]),                      \
+                                     (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + wave * 1024), 16, 0, 0);  \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][1] + (long)(kt) * kstep[(x) >> 1]),                      \
+                                     (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + (wave + 8) * 1024), 16, 0, 0); \
+  } while (0)
+#define DW_WAIT(issued)                                                                                          \
+  do {                                                                                                           \
+    if (issued) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                 \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                        \
+  } while (0)
+
+  f32x4 acc[2][2][MI][NJ];
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fk = lane >> 4;
+  int a_o[MI][2], b_o[NJ][2];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int row = wr * (MI * 16) + i * 16 + frow;
+    a_o[i][0] = row * 128 + ((fk ^ swz3(row)) << 4);
+    a_o[i][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int row = wc * (NJ * 16) + j * 16 + frow;
+    b_o[j][0] = row * 128 + ((fk ^ swz3(row)) << 4);
+    b_o[j][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+  }
+
+  bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
+#define DW_READ_A(st, qm)                                                                                        \
+  _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
+    fa[i][0] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[i][0]);                               \
+    fa[i][1] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[i][1]);                               \
+  }
+#define DW_READ_B(st, qn, fb)                                                                                    \
+  _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
+    fb[j][0] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                  \
+    fb[j][1] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                  \
+  }
+#define DW_MFMA(qm, qn, fb)                                                                                      \
+  do {                                                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_setprio(1);                                                                               \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                               \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                               \
+        acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[qm][qn][i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                \
+  } while (0)
+
+  // prologue: K-tile 0 complete, A0 / B0 of K-tile 1 in flight
+  DW_ISSUE(0, 0); DW_ISSUE(2, 0); DW_ISSUE(3, 0); DW_ISSUE(1, 0);
+  if (nk > 1) {
+    DW_ISSUE(0, 1); DW_ISSUE(2, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();  // stagger
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    DW_READ_B(st, 0, fb0);
+    __builtin_amdgcn_sched_barrier(0);
+    DW_READ_A(st, 0);
+    if (n1) DW_ISSUE(3, kt + 1);
+    DW_WAIT(n1);
+    DW_MFMA(0, 0, fb0);
+    DW_READ_B(st, 1, fb1);
+    if (n1) DW_ISSUE(1, kt + 1);
+    DW_WAIT(n1);
+    DW_MFMA(0, 1, fb1);
+    DW_READ_A(st, 1);
+    if (n2) DW_ISSUE(0, kt + 2);
+    DW_WAIT(n2);
+    DW_MFMA(1, 1, fb1);
+    if (n2) DW_ISSUE(2, kt + 2);
+    DW_WAIT(n2);
+    DW_MFMA(1, 0, fb0);
+  }
+  if (!late) __builtin_amdgcn_s_barrier();
+#undef DW_ISSUE
+#undef DW_WAIT
+#undef DW_READ_A
+#undef DW_READ_B
+#undef DW_MFMA
+
+  // epilogue: lane & 15 -> output row (dY column), 4 * (lane >> 4) + reg -> 4 consecutive output columns
+#pragma unroll
+  for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = row0 + qm * AH + wr * (MI * 16) + i * 16 + (lane & 15);
+      if (m >= P.M) continue;
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int n0 = col0 + qn * BH + wc * (NJ * 16) + j * 16 + 4 * (lane >> 4);
+          if (n0 >= P.N) continue;
+          const long o = (long)m * P.ldo + n0;
+          f32x4 v = acc[qm][qn][i][j];
+          if (n0 + 3 < P.N) {
+            if (P.mask) {
+              const float4 mk = *reinterpret_cast<const float4*>(P.mask + o);
+              v[0] *= mk.x; v[1] *= mk.y; v[2] *= mk.z; v[3] *= mk.w;
+            }
+            if (ga.accumulate) {
+              const float4 old = *reinterpret_cast<const float4*>(P.out + o);
+              v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+            }
+            *reinterpret_cast<float4*>(P.out + o) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            for (int r = 0; r < 4 && n0 + r < P.N; ++r) {
+              float x = v[r];
+              if (P.mask) x *= P.mask[o + r];
+              if (ga.accumulate) x += P.out[o + r];
+              P.out[o + r] = x;
+            }
+          }
+        }
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace
+
+extern "C" int64_t vl_blocked_elems(int64_t M, int64_t N) { return ((M + 63) / 64) * 64 * N; }
+
+// tab: HOST array of n x VL_TR_FIELDS int64 {src, ld, N, dst, colsum_partial (0 = none), 0}
+extern "C" int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, void* stream) {
+  VL_CHECK_ARG(tab && n >= 1 && n <= MAXT && M >= 1 && M < (1LL << 31), "vl_transpose_blocked: bad arguments");
+  TrArgs a{};
+  a.n = (int)n; a.M = (int)M; a.mblocks = (int)((M + 63) / 64);
+  int units = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t* t = tab + i * VL_TR_FIELDS;
+    TrEntry& e = a.e[i];
+    e.src = (const bf16_raw*)t[0]; e.ld = t[1]; e.N = (int)t[2]; e.dst = (bf16_raw*)t[3]; e.colsum = (float*)t[4];
+    VL_CHECK_ARG(e.src && e.dst && e.N > 0 && (e.N & 63) == 0 && e.ld >= e.N && (e.ld & 7) == 0 && al16(e.src) && al16(e.dst),
+                 "vl_transpose_blocked: entry %d: N must be a multiple of 64, ld a multiple of 8, pointers 16-byte aligned", i);
+    e.unit0 = units;
+    units += a.mblocks * (e.N >> 6);
+  }
+  a.total_units = units;
+  int grid = units < 4096 ? units : 4096;
+  hipLaunchKernelGGL(transpose_blocked_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  VL_CHECK_LAUNCH("vl_transpose_blocked");
+  return 0;
+}
+
+extern "C" int vl_colsum_finalize(const float* partial, int64_t nblk, int64_t N, float* const* outs, int64_t nout,
+                                  int accumulate, void* stream) {
+  VL_CHECK_ARG(partial && outs && nblk >= 1 && N >= 1 && nout >= 1 && nout <= 4 && N % nout == 0,
+               "vl_colsum_finalize: bad arguments");
+  CsArgs a{};
+  a.partial = partial; a.nblk = (int)nblk; a.N = (int)N; a.seg = (int)(N / nout); a.accumulate = accumulate;
+  for (int i = 0; i < nout; ++i) {
+    VL_CHECK_ARG(outs[i], "vl_colsum_finalize: null destination %d", i);
+    a.out[i] = outs[i];
+  }
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
+  VL_CHECK_LAUNCH("vl_colsum_finalize");
+  return 0;
+}
+
+// probs: HOST array of nprob x VL_DW_FIELDS int64 {aT, a_rows_total, bT, b_rows_total, out, ldo, mask (0 = none), M, N, 0}
+extern "C" int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream) {
+  VL_CHECK_ARG(probs && nprob >= 1 && nprob <= MAXT && K >= 1, "vl_dw_grouped: bad arguments");
+  DwArgs a{};
+  a.nprob = (int)nprob; a.nk = (int)((K + 63) / 64); a.accumulate = accumulate;
+  int tiles = 0;
+  for (int i = 0; i < nprob; ++i) {
+    const int64_t* t = probs + i * VL_DW_FIELDS;
+    DwProb& p = a.p[i];
+    p.a = (const bf16_raw*)t[0]; p.ka = t[1] * 64; p.b = (const bf16_raw*)t[2]; p.kb = t[3] * 64;
+    p.out = (float*)t[4]; p.ldo = t[5]; p.mask = (const float*)t[6]; p.M = (int)t[7]; p.N = (int)t[8];
+    VL_CHECK_ARG(p.a && p.b && p.out && p.M > 0 && p.N > 0 && t[1] >= p.M && t[3] >= p.N && p.ldo >= p.N,
+                 "vl_dw_grouped: problem %d: bad pointers / sizes", i);
+    VL_CHECK_ARG(al16(p.a) && al16(p.b) && al16(p.out) && al16(p.mask) && (p.ldo & 3) == 0,
+                 "vl_dw_grouped: problem %d: pointers must be 16-byte aligned, ldo a multiple of 4", i);
+    p.tile0 = tiles;
+    p.tiles_n = (p.N + 255) / 256;
+    tiles += ((p.M + 255) / 256) * p.tiles_n;
+  }
+  a.total_tiles = tiles;
+  const size_t lds = 2 * 65536;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_grouped_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vl_set_error(-3, "vl_dw_grouped: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(dw_grouped_kernel, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a);
+  VL_CHECK_LAUNCH("vl_dw_grouped");
+  return 0;
+}

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
 // out_k[c] = sum_blk ws[blk][k][c]; 256 threads = 16 columns x 16 row-groups, LDS combine.  blockIdx.y selects one
 // of up to two independent reductions (the two LayerNorms of a transformer layer share one launch).
 struct LnReduceSet { const float* ws; int nblk; float* dgamma; float* dbeta; float* dbias; };
-struct LnReduceArgs { LnReduceSet set[2]; int H; };
+struct LnReduceArgs { LnReduceSet set[2]; int H; int accumulate; };
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(LnReduceArgs a) {
   __shared__ float red[16][17];
   const LnReduceSet& r = a.set[blockIdx.y];
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(LnReduceArgs a) {
     for (int j = 0; j < 16; ++j) t += red[j][tx];
     const int k = idx / H, c = idx - k * H;
     float* dst = k == 0 ? r.dgamma : (k == 1 ? r.dbeta : r.dbias);
-    if (dst) dst[c] = t;
+    if (dst) dst[c] = a.accumulate ? dst[c] + t : t;
   }
 }
 
@@ -326,13 +326,14 @@ extern "C" int vl_ln_bwd_reduce(const float* partial_ws, int64_t M, int64_t H, f
 // Two such reductions in one launch (the two LayerNorms of a transformer layer: 12 launches of ~20 us less per step).
 extern "C" int vl_ln_bwd_reduce2(const float* ws_a, int64_t M_a, float* dgamma_a, float* dbeta_a, float* dbias_a,
                                  const float* ws_b, int64_t M_b, float* dgamma_b, float* dbeta_b, float* dbias_b,
-                                 int64_t H, void* stream) {
+                                 int64_t H, int accumulate, void* stream) {
   if (int rc = check_shape("vl_ln_bwd_reduce2", M_a, H, 1, 0.f, 0.f)) return rc;
   VL_CHECK_ARG(ws_a && ws_b && M_b > 0, "vl_ln_bwd_reduce2: bad arguments");
   LnReduceArgs ra{};
   ra.set[0] = LnReduceSet{ws_a, nblk_for(M_a), dgamma_a, dbeta_a, dbias_a};
   ra.set[1] = LnReduceSet{ws_b, nblk_for(M_b), dgamma_b, dbeta_b, dbias_b};
   ra.H = (int)H;
+  ra.accumulate = accumulate;
   hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((unsigned)((3 * H + 15) / 16), 2), dim3(256), 0, (hipStream_t)stream, ra);
   VL_CHECK_LAUNCH("vl_ln_bwd_reduce2");
   return 0;

@@ -1,0 +1,181 @@
+// vl_stack_fwd / vl_stack_bwd: the layer sequencing of the transformer trunk in native code.
+//
+// Reference: BertEncoder.forward (volta/volta/encoders.py:848-892) walks 24 sub-layers from Python, and autograd
+// replays them backwards; every op is a separate eager dispatch.  Here one C call enqueues the whole stack -- per
+// layer { QKV projection -> attention -> out-projection -> dropout+residual+LayerNorm -> FFN1 (+GELU) -> FFN2 ->
+// dropout+residual+LayerNorm [-> * row mask] } -- from a descriptor the host builds ONCE per (batch shape, parameter
+// placement): no interpreter, allocator or binding cost per kernel (the Python driver needed ~10 ctypes calls and ~12
+// allocations per layer and direction, 6-13 ms of host time per step).
+//
+// Backward: the critical path (LayerNorm / dX GEMMs / attention) runs on `stream_main`; everything that only feeds the
+// optimizer -- the K-major re-layout of the operands, the bias / LayerNorm column sums and the grouped weight-gradient
+// GEMM (csrc/dw.hip) -- is forked per layer onto `stream_side`, where it fills the CUs the critical path leaves idle.
+// The caller joins the streams (after the embedding backward).  Gradients are written straight to the 16 destinations
+// the descriptor names (the optimizer's flat arena), optionally accumulating.
+//
+// The library keeps no state: every buffer, both streams and the fork event belong to the caller.
+#include <string.h>
+
+#include "common.h"
+#include "../../include/vlhip.h"
+
+namespace {
+
+inline float f_of(int64_t bits) {
+  const uint32_t u = (uint32_t)bits;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+template <class T> inline T* ptr(int64_t v) { return reinterpret_cast<T*>(static_cast<uintptr_t>(v)); }
+inline uint64_t seed_of(int64_t seed0, int site) { return ((uint64_t)seed0 * 4096ull + (uint64_t)site); }
+
+#define VL_TRY(call) do { if (int rc_ = (call)) return rc_; } while (0)
+
+// vl_gemm_nt, optionally bracketed by a caller-owned event pair (descriptor field VL_ST_PROF)
+int gemm(int64_t* prof, const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
+         int64_t M, int64_t N, int64_t K, int passes, int epi, const float* bias, const float* resid, float* out32,
+         int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream) {
+  int64_t* pair = nullptr;
+  if (prof) {
+    const int64_t n = prof[2]++;
+    if (prof[0] > 0 && n % prof[0] == 0 && prof[3] < prof[1]) pair = prof + VL_PROF_HEADER + VL_PROF_PAIR * prof[3]++;
+  }
+  if (pair) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(pair[0])), (hipStream_t)stream);
+  const int rc = vl_gemm_nt(a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, passes, epi, bias, resid, out32, ldc, out_hi, out_lo,
+                            aux16, ld16, stream);
+  if (pair) {
+    (void)hipEventRecord(reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(pair[1])), (hipStream_t)stream);
+    pair[2] = passes * 16 + epi;
+    pair[3] = 2 * M * N * K;
+  }
+  return rc;
+}
+
+int check_header(const char* fn, const int64_t* d) {
+  VL_CHECK_ARG(d, "%s: null descriptor", fn);
+  VL_CHECK_ARG(d[VL_ST_MAGIC] == VL_ST_MAGIC_VALUE, "%s: descriptor magic mismatch (built for another library version?)", fn);
+  VL_CHECK_ARG(d[VL_ST_B] > 0 && d[VL_ST_S] > 0 && d[VL_ST_H] > 0 && d[VL_ST_I] > 0 && d[VL_ST_NH] > 0 && d[VL_ST_NLAYERS] > 0,
+               "%s: bad dimensions in the descriptor", fn);
+  VL_CHECK_ARG(d[VL_ST_H] == d[VL_ST_NH] * 64, "%s: head dim must be 64", fn);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t vl_stack_desc_len(int64_t n_layers) { return VL_ST_FIELDS + n_layers * VL_LY_FIELDS; }
+
+extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer_end, void* stream) {
+  VL_TRY(check_header("vl_stack_fwd", d));
+  const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I], nh = d[VL_ST_NH], L = d[VL_ST_NLAYERS];
+  VL_CHECK_ARG(layer_begin >= 0 && layer_begin <= layer_end && layer_end <= L, "vl_stack_fwd: bad layer range");
+  const int64_t M = B * S;
+  const float eps = f_of(d[VL_ST_EPS]), p_hid = f_of(d[VL_ST_P_HID]), p_att = f_of(d[VL_ST_P_ATT]);
+  const float* addmask = ptr<const float>(d[VL_ST_ADDMASK]);
+  const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
+  int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
+  for (int64_t l = layer_begin; l < layer_end; ++l) {
+    const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
+    const int s3 = (int)(16 * l + 3);
+    // Q | K | V = X W^T + b, written as the (hi, lo) split the attention kernel reads
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_X_HI]), ptr<void>(y[VL_LY_X_LO]), H, ptr<void>(y[VL_LY_WQKV_HI]), ptr<void>(y[VL_LY_WQKV_LO]), H,
+                      M, 3 * H, H, 3, VL_EPI_SPLIT, ptr<const float>(y[VL_LY_BQKV]), nullptr, nullptr, 0,
+                      ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), nullptr, 3 * H, stream));
+    VL_TRY(vl_attn2_fwd(ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), addmask, ptr<void>(y[VL_LY_CTX_HI]),
+                        ptr<void>(y[VL_LY_CTX_LO]), ptr<float>(y[VL_LY_LSE]), B, S, nh, 64, S, p_att, seed_of(d[VL_ST_SEED0], s3), stream));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_CTX_HI]), ptr<void>(y[VL_LY_CTX_LO]), H, ptr<void>(y[VL_LY_WO_HI]), ptr<void>(y[VL_LY_WO_LO]), H,
+                      M, H, H, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_BO]), nullptr, ptr<float>(y[VL_LY_Z1]), H, nullptr, nullptr,
+                      nullptr, 0, stream));
+    VL_TRY(vl_ln_fwd(ptr<float>(y[VL_LY_Z1]), ptr<const float>(y[VL_LY_X32]), nullptr, 1, nullptr, nullptr,
+                     ptr<const float>(y[VL_LY_LN1_G]), ptr<const float>(y[VL_LY_LN1_B]), eps, ptr<float>(y[VL_LY_X1_32]),
+                     ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), ptr<float>(y[VL_LY_MEAN1]), ptr<float>(y[VL_LY_RSTD1]),
+                     M, H, M, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 1), stream));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), H, ptr<void>(y[VL_LY_W1_HI]), ptr<void>(y[VL_LY_W1_LO]), H,
+                      M, I, H, 3, VL_EPI_GELU_SPLIT, ptr<const float>(y[VL_LY_B1]), nullptr, nullptr, 0, ptr<void>(y[VL_LY_H_HI]),
+                      ptr<void>(y[VL_LY_H_LO]), ptr<void>(y[VL_LY_U16]), I, stream));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_H_HI]), ptr<void>(y[VL_LY_H_LO]), I, ptr<void>(y[VL_LY_W2_HI]), ptr<void>(y[VL_LY_W2_LO]), I,
+                      M, H, I, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_B2]), nullptr, ptr<float>(y[VL_LY_Z2]), H, nullptr, nullptr,
+                      nullptr, 0, stream));
+    VL_TRY(vl_ln_fwd(ptr<float>(y[VL_LY_Z2]), ptr<const float>(y[VL_LY_X1_32]), nullptr, 1, nullptr, row_post,
+                     ptr<const float>(y[VL_LY_LN2_G]), ptr<const float>(y[VL_LY_LN2_B]), eps, ptr<float>(y[VL_LY_OUT32]),
+                     ptr<void>(y[VL_LY_OUT_HI]), ptr<void>(y[VL_LY_OUT_LO]), ptr<float>(y[VL_LY_MEAN2]), ptr<float>(y[VL_LY_RSTD2]),
+                     M, H, M, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 2), stream));
+  }
+  return 0;
+}
+
+// layers [layer_lo, layer_hi) in DESCENDING order.  dy of the top layer = y[VL_LY_DY] of layer layer_hi - 1; each layer
+// writes dL/d(its input) to y[VL_LY_DX] (the host makes DX of layer l the DY of layer l - 1).
+extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo, void* stream_main, void* stream_side) {
+  VL_TRY(check_header("vl_stack_bwd", d));
+  const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I], nh = d[VL_ST_NH], L = d[VL_ST_NLAYERS];
+  VL_CHECK_ARG(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi <= L, "vl_stack_bwd: bad layer range");
+  const int64_t M = B * S;
+  const float p_hid = f_of(d[VL_ST_P_HID]), p_att = f_of(d[VL_ST_P_ATT]);
+  const float* addmask = ptr<const float>(d[VL_ST_ADDMASK]);
+  const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
+  const int accumulate = (int)d[VL_ST_ACCUMULATE];
+  int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
+  hipStream_t sm = (hipStream_t)stream_main;
+  hipStream_t ss = stream_side ? (hipStream_t)stream_side : sm;
+  hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);
+  VL_CHECK_ARG(ss == sm || fork, "vl_stack_bwd: a side stream needs the fork event of the descriptor");
+  const int64_t mblk = (M + 63) / 64;
+  for (int64_t l = layer_hi - 1; l >= layer_lo; --l) {
+    const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
+    const int s3 = (int)(16 * l + 3);
+    // ---- critical path ------------------------------------------------------------------------------------------
+    VL_TRY(vl_ln_bwd(ptr<const float>(y[VL_LY_DY]), ptr<const float>(y[VL_LY_Z2]), ptr<const float>(y[VL_LY_MEAN2]),
+                     ptr<const float>(y[VL_LY_RSTD2]), ptr<const float>(y[VL_LY_LN2_G]), nullptr, row_post, ptr<float>(y[VL_LY_DZ2]),
+                     ptr<void>(y[VL_LY_DT2]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS2]), M, H, M, 0, 0, p_hid, 0.f,
+                     seed_of(d[VL_ST_SEED0], s3 + 2), sm));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT2]), nullptr, H, ptr<void>(y[VL_LY_W2_T]), nullptr, H, M, I, H, 1, VL_EPI_DGELU_BF16,
+                      nullptr, nullptr, nullptr, 0, ptr<void>(y[VL_LY_DU16]), nullptr, ptr<void>(y[VL_LY_U16]), I, sm));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DU16]), nullptr, I, ptr<void>(y[VL_LY_W1_T]), nullptr, I, M, H, I, 1, VL_EPI_F32, nullptr,
+                      ptr<const float>(y[VL_LY_DZ2]), ptr<float>(y[VL_LY_DX1]), H, nullptr, nullptr, nullptr, 0, sm));
+    VL_TRY(vl_ln_bwd(ptr<const float>(y[VL_LY_DX1]), ptr<const float>(y[VL_LY_Z1]), ptr<const float>(y[VL_LY_MEAN1]),
+                     ptr<const float>(y[VL_LY_RSTD1]), ptr<const float>(y[VL_LY_LN1_G]), nullptr, nullptr, ptr<float>(y[VL_LY_DZ1]),
+                     ptr<void>(y[VL_LY_DT1]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS1]), M, H, M, 0, 0, p_hid, 0.f,
+                     seed_of(d[VL_ST_SEED0], s3 + 1), sm));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT1]), nullptr, H, ptr<void>(y[VL_LY_WO_T]), nullptr, H, M, H, H, 1, VL_EPI_BF16, nullptr,
+                      nullptr, nullptr, 0, ptr<void>(y[VL_LY_DCTX16]), nullptr, nullptr, H, sm));
+    VL_TRY(vl_attn2_bwd(ptr<void>(y[VL_LY_QKV_HI]), addmask, ptr<void>(y[VL_LY_DCTX16]), ptr<const float>(y[VL_LY_LSE]),
+                        ptr<void>(y[VL_LY_DQKV]), B, S, nh, 64, S, p_att, seed_of(d[VL_ST_SEED0], s3), sm));
+    if (ss != sm) {  // everything the side stream reads of this layer has been enqueued on the main stream
+      hipError_t e = hipEventRecord(fork, sm);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ss, fork, 0);
+      if (e != hipSuccess) return vl_set_error(-3, "vl_stack_bwd: stream fork: %s", hipGetErrorString(e));
+    }
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DQKV]), nullptr, 3 * H, ptr<void>(y[VL_LY_WQKV_T]), nullptr, 3 * H, M, H, 3 * H, 1, VL_EPI_F32,
+                      nullptr, ptr<const float>(y[VL_LY_DZ1]), ptr<float>(y[VL_LY_DX]), H, nullptr, nullptr, nullptr, 0, sm));
+    // ---- optimizer-only work: K-major re-layout, column sums, grouped weight-gradient GEMM ---------------------------
+    const int64_t tr[8 * VL_TR_FIELDS] = {
+        y[VL_LY_DQKV], 3 * H, 3 * H, d[VL_ST_T_DQKV], d[VL_ST_CS_QKV], 0,
+        y[VL_LY_DT1], H, H, d[VL_ST_T_DT1], 0, 0,
+        y[VL_LY_DU16], I, I, d[VL_ST_T_DU], d[VL_ST_CS_U], 0,
+        y[VL_LY_DT2], H, H, d[VL_ST_T_DT2], 0, 0,
+        y[VL_LY_X_HI], H, H, d[VL_ST_T_X], 0, 0,
+        y[VL_LY_CTX_HI], H, H, d[VL_ST_T_CTX], 0, 0,
+        y[VL_LY_X1_HI], H, H, d[VL_ST_T_X1], 0, 0,
+        y[VL_LY_H_HI], I, I, d[VL_ST_T_H], 0, 0};
+    VL_TRY(vl_transpose_blocked(tr, 8, M, ss));
+    float* const* g = reinterpret_cast<float* const*>(y + VL_LY_GRAD0);  // 16 destinations, LayerSpec.params order
+    float* bq[3] = {ptr<float>(y[VL_LY_GRAD0 + 1]), ptr<float>(y[VL_LY_GRAD0 + 3]), ptr<float>(y[VL_LY_GRAD0 + 5])};
+    float* b1[1] = {ptr<float>(y[VL_LY_GRAD0 + 11])};
+    (void)g;
+    VL_TRY(vl_colsum_finalize(ptr<const float>(d[VL_ST_CS_QKV]), mblk, 3 * H, bq, 3, accumulate, ss));
+    VL_TRY(vl_colsum_finalize(ptr<const float>(d[VL_ST_CS_U]), mblk, I, b1, 1, accumulate, ss));
+    VL_TRY(vl_ln_bwd_reduce2(ptr<const float>(y[VL_LY_LNWS2]), M, ptr<float>(y[VL_LY_GRAD0 + 14]), ptr<float>(y[VL_LY_GRAD0 + 15]),
+                             ptr<float>(y[VL_LY_GRAD0 + 13]), ptr<const float>(y[VL_LY_LNWS1]), M, ptr<float>(y[VL_LY_GRAD0 + 8]),
+                             ptr<float>(y[VL_LY_GRAD0 + 9]), ptr<float>(y[VL_LY_GRAD0 + 7]), H, accumulate, ss));
+    const int64_t pr[6 * VL_DW_FIELDS] = {
+        d[VL_ST_T_DQKV], 3 * H, d[VL_ST_T_X], H, y[VL_LY_GRAD0 + 0], H, y[VL_LY_MASK0 + 0], H, H, 0,
+        d[VL_ST_T_DQKV] + 2 * 64 * H, 3 * H, d[VL_ST_T_X], H, y[VL_LY_GRAD0 + 2], H, y[VL_LY_MASK0 + 1], H, H, 0,
+        d[VL_ST_T_DQKV] + 2 * 64 * 2 * H, 3 * H, d[VL_ST_T_X], H, y[VL_LY_GRAD0 + 4], H, y[VL_LY_MASK0 + 2], H, H, 0,
+        d[VL_ST_T_DT1], H, d[VL_ST_T_CTX], H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
+        d[VL_ST_T_DU], I, d[VL_ST_T_X1], H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, 0,
+        d[VL_ST_T_DT2], H, d[VL_ST_T_H], I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
+    VL_TRY(vl_dw_grouped(pr, 6, M, accumulate, ss));
+  }
+  return 0;
+}

@@ -59,10 +59,7 @@ class NativeLinearFunction(torch.autograd.Function):
         dy16[:, :N] = dy
         dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
         ops.gemm_nt(dy16, None, pw.t_hi, None, M, K, Np, 1, EPI_F32, out32=dx)
-        dw = dw_gemm(dy16[:, :N], x_hi, M, N, K)
-        mask = linear_params(ctx.module)[1]
-        if mask is not None:
-            ops.mask_mul(dw, mask, dw)
+        dw = dw_gemm(dy16[:, :N], x_hi, M, N, K, mask=linear_params(ctx.module)[1])
         return dx, dw, dy.sum(0), None
 
 

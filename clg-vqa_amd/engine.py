@@ -14,10 +14,14 @@ Data layout in HBM (B = batch, T text tokens, V boxes, S = T + V, M = B*S rows, 
   qkv32   [M,3H] fp32, columns [Q|K|V]             ctx (hi,lo) [M,H] bf16
   u16/h   [M,I] bf16 pre-activation / GELU output  weights: (hi,lo) [N,K] + transposed hi [K,N], rebuilt per step
 """
+import numpy as np
 import torch
 
-from . import ops
+from . import _lib, ops
+from ._lib import header_constants
 from .ops import BF16, EPI_BF16, EPI_DGELU_BF16, EPI_F32, EPI_GELU_SPLIT
+
+VL = header_constants()  # VL_ST_* / VL_LY_* descriptor field indices, parsed from include/vlhip.h
 
 
 def _ceil8(n):
@@ -44,7 +48,10 @@ class PreparedWeight(object):
         self.hi = torch.empty(self.N, self.K, dtype=BF16, device=device)
         self.lo = torch.empty(self.N, self.K, dtype=BF16, device=device)
         self.t_hi = torch.zeros(self.K, self.Np, dtype=BF16, device=device) if need_t else None
-        self.bias = None
+        # the bias the GEMM epilogue reads: the parameter itself for one Linear, a persistent packed buffer for Q|K|V
+        # (stable pointers: the native stack descriptor holds them)
+        self.bias = (linears[0].bias.detach() if len(linears) == 1
+                     else torch.empty(self.N, dtype=torch.float32, device=device))
         self.key = None
 
     def _key(self):
@@ -68,9 +75,16 @@ class PreparedWeight(object):
             r += n
         return rows
 
+    def _pack_bias(self):
+        if len(self.linears) == 1:
+            b = self.linears[0].bias.detach()
+            if b.data_ptr() != self.bias.data_ptr():
+                self.bias = b
+        else:
+            torch.cat([l.bias.detach() for l in self.linears], out=self.bias)
+
     def refresh_bias(self, fingerprint=True):
-        self.bias = (self.linears[0].bias.detach() if len(self.linears) == 1
-                     else torch.cat([l.bias.detach() for l in self.linears]))
+        self._pack_bias()
         # after an explicit mark_dirty() the version fingerprint is left empty: the next call that is not preceded by
         # an optimizer step sees a mismatch, prepares once more and records the real fingerprint
         self.key = self._key() if fingerprint else None
@@ -86,8 +100,7 @@ class PreparedWeight(object):
             ops.weight_prep(w.detach(), m, self.hi[r:r + n], self.lo[r:r + n],
                             None if self.t_hi is None else self.t_hi[:, r:r + n])
             r += n
-        self.bias = (self.linears[0].bias.detach() if len(self.linears) == 1
-                     else torch.cat([l.bias.detach() for l in self.linears]))
+        self._pack_bias()
         self.key = key
 
 
@@ -96,20 +109,33 @@ def _src_ptrs(lin):
     return (w.data_ptr(), 0 if m is None else m.data_ptr())
 
 
-def dw_gemm(dy16, x16, M, N, K):
-    """dW[N,K] = dY[M,N]^T . X[M,K] (bf16 operands, fp32 out) as an NT GEMM over transposed copies."""
+def dw_gemm(dy16, x16, M, N, K, mask=None):
+    """dW[N,K] = dY[M,N]^T . X[M,K] (bf16 operands, fp32 out; optional SFT mask in the epilogue).  Feature sizes that
+    are multiples of 64 go through the K-major path of the layer stack (csrc/dw.hip); anything else (the 1842-label
+    classifier) through transposed copies + the split-K NT kernel."""
     dev = dy16.device
     dW = torch.empty(N, K, dtype=torch.float32, device=dev)
-    if ops.gemm_tn_splitk(dy16, x16, N, K, M, dW):
+    if N % 64 == 0 and K % 64 == 0 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0:
+        lib = _lib.lib()
+        tA = ops._tmp(torch.empty(lib.vl_blocked_elems(M, N), dtype=BF16, device=dev))
+        tB = ops._tmp(torch.empty(lib.vl_blocked_elems(M, K), dtype=BF16, device=dev))
+        ops.transpose_blocked([(dy16, tA, None), (x16, tB, None)], M)
+        ops.dw_grouped([(tA, 0, N, tB, K, dW, mask, N, K)], M)
         return dW
+    if ops.gemm_tn_splitk(dy16, x16, N, K, M, dW):
+        return dW if mask is None else ops.mask_mul(dW, mask, dW)
     Mp = _ceil8(M)
-    alloc = torch.zeros if Mp != M else torch.empty
-    dyT = ops._tmp(alloc(N, Mp, dtype=BF16, device=dev))
-    xT = ops._tmp(alloc(K, Mp, dtype=BF16, device=dev))
+    # (torch.zeros would fill on torch's current stream while the launches below may be routed to another one:
+    # the pad columns are zeroed by a native memset on the launch stream instead)
+    dyT = ops._tmp(torch.empty(N, Mp, dtype=BF16, device=dev))
+    xT = ops._tmp(torch.empty(K, Mp, dtype=BF16, device=dev))
+    if Mp != M:
+        ops.memset_zero(dyT)
+        ops.memset_zero(xT)
     ops.transpose_bf16(dy16, dyT, M, N)
     ops.transpose_bf16(x16, xT, M, K)
     ops.gemm_nt_splitk(dyT, xT, N, K, Mp, dW)
-    return dW
+    return dW if mask is None else ops.mask_mul(dW, mask, dW)
 
 
 class LayerSpec(object):
@@ -137,216 +163,228 @@ def _masked(dw, lin):
     return dw
 
 
+def _f32_bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+class StackArena(object):
+    """Device buffers of the layer stack for one (B, S) shape, allocated ONCE and re-used every step (no allocator
+    traffic on the hot path; sized for 288 GB of HBM: ~0.55 GB per layer at c2):
+
+    * the stream between layers (fp32 + its (hi, lo) split) -- ``x_hi`` per layer, it is the X operand of the layer's
+      weight gradients; fp32 and lo ping-pong;
+    * the activations backward reads, per layer when gradients are needed (one shared set for inference);
+    * backward buffers: those the weight-gradient stream reads (dt2, du16, dt1, dqkv, LayerNorm partials) are private
+      to a layer, the rest of the critical path shares one set;
+    * scratch of the weight-gradient stream: the K-major images of the eight GEMM operands, column-sum partials."""
+
+    def __init__(self, L, B, S, H, I, nh, device, need_grad):
+        self.key = (L, B, S, H, I, nh, str(device), need_grad)
+        self.L, self.B, self.S, self.need_grad = L, B, S, need_grad
+        M = B * S
+        n = L if need_grad else 1
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)  # noqa: E731
+        b16 = lambda *s: torch.empty(*s, dtype=BF16, device=device)  # noqa: E731
+        self.x32, self.x_lo = f32(2, M, H), b16(2, M, H)
+        self.x_hi = b16(n + 1, M, H)
+        self.qkv_hi, self.qkv_lo = b16(n, M, 3 * H), b16(n, M, 3 * H)
+        self.ctx_hi, self.ctx_lo, self.lse = b16(n, M, H), b16(n, M, H), f32(n, B * nh * S)
+        self.z1, self.mean1, self.rstd1 = f32(n, M, H), f32(n, M), f32(n, M)
+        self.x1_32, self.x1_hi, self.x1_lo = f32(M, H), b16(n, M, H), b16(M, H)
+        self.u16, self.h_hi, self.h_lo = b16(n, M, I), b16(n, M, I), b16(M, I)
+        self.z2, self.mean2, self.rstd2 = f32(n, M, H), f32(n, M), f32(n, M)
+        self.addmask, self.row_post = f32(M), f32(M)
+        self.in_flight = False  # a training forward whose backward has not run yet owns the saved activations
+        if need_grad:
+            lib = _lib.lib()
+            self.dbuf = f32(2, M, H)
+            self.dz2, self.dx1, self.dz1, self.dctx16 = f32(M, H), f32(M, H), f32(M, H), b16(M, H)
+            self.dt2, self.du16, self.dt1, self.dqkv = b16(L, M, H), b16(L, M, I), b16(L, M, H), b16(L, M, 3 * H)
+            nws = lib.vl_ln_bwd_ws_floats(M, H)
+            self.lnws1, self.lnws2 = f32(L, nws), f32(L, nws)
+            img = lambda N: b16(lib.vl_blocked_elems(M, N))  # noqa: E731
+            self.t_dqkv, self.t_dt1, self.t_du, self.t_dt2 = img(3 * H), img(H), img(I), img(H)
+            self.t_x, self.t_ctx, self.t_x1, self.t_h = img(H), img(H), img(H), img(I)
+            mb = (M + 63) // 64
+            self.cs_qkv, self.cs_u = f32(mb, 3 * H), f32(mb, I)
+            self.fork = torch.cuda.Event()
+            self.fork.record()  # materialises the hipEvent_t behind the handle
+
+    def lay(self, t, l):
+        return t[l if self.need_grad else 0]
+
+
 class LayerStack(object):
-    """N x { QKV GEMM -> fused attention -> out-proj GEMM -> dropout+residual+LN -> FFN1 GEMM (+GELU) -> FFN2 GEMM ->
-    dropout+residual+LN [-> * row mask] } on the single [B*S, H] stream, forward and backward."""
+    """N x { QKV GEMM -> attention -> out-proj GEMM -> dropout+residual+LN -> FFN1 GEMM (+GELU) -> FFN2 GEMM ->
+    dropout+residual+LN [-> * row mask] } on the single [B*S, H] stream.  The sequencing itself is native
+    (csrc/stack.hip: ONE call per direction); this class owns the buffers and the descriptor the native side walks."""
 
     def __init__(self, specs, H, nh, I, eps):
         self.specs, self.H, self.nh, self.I, self.eps = specs, H, nh, I, eps
-        # weight-gradient GEMMs (dW = dY^T X, bias column sums) are off the backward critical path: they run on a
-        # second HIP stream so that their workgroups fill the CUs the dX / LayerNorm / attention kernels leave idle
-        self.overlap_dw = True
-        self._pending = None
-        self.side_reduce = False  # LayerNorm-backward column sums on the weight-gradient stream: measured +0.1 ms (that stream is the longer one)
-        self.pair_reduce = True  # the two LayerNorm-backward column-sum reductions of a layer share one launch
-        self.early_join = False  # A/B knob: join the streams at the end of the layer stack instead of the trunk
+        self.overlap_dw = True   # weight-gradient work on a second HIP stream (A/B knob)
         self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
         # callable(layer) -> (16 destination views in LayerSpec.params order, accumulate) or None: when the optimizer
-        # provides it, the weight-gradient GEMMs write straight into its flat gradient arena (no gradient copies)
+        # provides it, gradients are written straight into its flat arena
         self.grad_sink = None
-        self._fork = None
-        self.group_dw = False  # one grouped launch per layer (ops.gemm_tn_grouped): measured equal in situ, see DESIGN.md
         self._side = None
+        self._pending = None
+        self._arenas = {}
+        self._desc = {}
+        self.prof = None  # numpy int64 VlProf block (bench.py): GEMM launch timing by caller-owned events
 
     def make_prepared(self, device):
         return [dict(qkv=PreparedWeight([sp.q, sp.k, sp.v], device), o=PreparedWeight([sp.o], device),
                      w1=PreparedWeight([sp.w1], device), w2=PreparedWeight([sp.w2], device)) for sp in self.specs]
 
-    def forward(self, pw_layers, x32, x_hi, x_lo, am, B, S, p_hid, p_att, seed, row_post=None):
-        H, I, nh, M, dev = self.H, self.I, self.nh, B * S, x32.device
-        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-        b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
-        saved = []
-        for l, (sp, lw) in enumerate(zip(self.specs, pw_layers)):
-            ls = dict(x_hi=x_hi)
-            qkv32 = f32(M, 3 * H)
-            ops.gemm_nt(x_hi, x_lo, lw["qkv"].hi, lw["qkv"].lo, M, 3 * H, H, 3, EPI_F32, bias=lw["qkv"].bias,
-                        out32=qkv32)
-            ctx_hi, ctx_lo, lse = b16(M, H), b16(M, H), f32(B * nh * S)
-            ops.attn_fwd(qkv32, am, ctx_hi, ctx_lo, lse, B, S, nh, 64, p_att, seed(16 * l + 3))
-            z1 = f32(M, H)
-            ops.gemm_nt(ctx_hi, ctx_lo, lw["o"].hi, lw["o"].lo, M, H, H, 3, EPI_F32, bias=lw["o"].bias, out32=z1)
-            x1_32, x1_hi, x1_lo, mean1, rstd1 = f32(M, H), b16(M, H), b16(M, H), f32(M), f32(M)
-            ops.ln_fwd(z1, x32, None, sp.ln1.weight.detach(), sp.ln1.bias.detach(), self.eps, x1_32, x1_hi, x1_lo,
-                       mean1, rstd1, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
-            u16, h_hi, h_lo = b16(M, I), b16(M, I), b16(M, I)
-            ops.gemm_nt(x1_hi, x1_lo, lw["w1"].hi, lw["w1"].lo, M, I, H, 3, EPI_GELU_SPLIT, bias=lw["w1"].bias,
-                        out_hi=h_hi, out_lo=h_lo, aux16=u16)
-            z2 = f32(M, H)
-            ops.gemm_nt(h_hi, h_lo, lw["w2"].hi, lw["w2"].lo, M, H, I, 3, EPI_F32, bias=lw["w2"].bias, out32=z2)
-            x2_32, x2_hi, x2_lo, mean2, rstd2 = f32(M, H), b16(M, H), b16(M, H), f32(M), f32(M)
-            ops.ln_fwd(z2, x1_32, None, sp.ln2.weight.detach(), sp.ln2.bias.detach(), self.eps, x2_32, x2_hi, x2_lo,
-                       mean2, rstd2, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
-            ls.update(qkv32=qkv32, ctx_hi=ctx_hi, ctx_lo=ctx_lo, lse=lse, z1=z1, mean1=mean1, rstd1=rstd1,
-                      x1_hi=x1_hi, u16=u16, h_hi=h_hi, z2=z2, mean2=mean2, rstd2=rstd2)
-            saved.append(ls)
-            x32, x_hi, x_lo = x2_32, x2_hi, x2_lo
-        return x32, x_hi, x_lo, saved
+    # ---- buffers + descriptor -------------------------------------------------------------------------------------
+    def arena(self, B, S, device, need_grad):
+        key = (B, S, str(device), need_grad)
+        lst = self._arenas.setdefault(key, [])
+        for a in lst:
+            if not a.in_flight:
+                return a
+        a = StackArena(len(self.specs), B, S, self.H, self.I, self.nh, device, need_grad)
+        lst.append(a)
+        if len(lst) > 4:
+            raise RuntimeError("clg_vqa_amd: more than 4 training forwards without a backward on one model")
+        return a
 
-    def backward(self, pw_layers, saved, dy, am, B, S, p_hid, p_att, seed, ws, row_post=None):
-        """dy [M,H] fp32 = dL/d(stack output).  Returns (dL/d(stack input), per-layer grads in LayerSpec.params order)."""
-        H, I, nh, M, dev = self.H, self.I, self.nh, B * S, dy.device
-        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
-        b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
-        layer_grads = [None] * len(self.specs)
+    def _descriptor(self, ar, pw_layers):
+        """numpy int64 descriptor of (arena, prepared weights, parameters, masks): rebuilt only when a pointer moved."""
+        ptrs = []
+        for sp, lw in zip(self.specs, pw_layers):
+            for k in ("qkv", "o", "w1", "w2"):
+                p = lw[k]
+                ptrs += [p.hi.data_ptr(), p.lo.data_ptr(), p.t_hi.data_ptr(), p.bias.data_ptr()]
+            ptrs += [sp.ln1.weight.data_ptr(), sp.ln1.bias.data_ptr(), sp.ln2.weight.data_ptr(), sp.ln2.bias.data_ptr()]
+            for lin in (sp.q, sp.k, sp.v, sp.o, sp.w1, sp.w2):
+                m = linear_params(lin)[1]
+                ptrs.append(0 if m is None else m.data_ptr())
+        fp = (id(ar), tuple(ptrs))
+        hit = self._desc.get(id(ar))
+        if hit is not None and hit[0] == fp:
+            return hit[1]
+        L = len(self.specs)
+        F, LF = VL["VL_ST_FIELDS"], VL["VL_LY_FIELDS"]
+        d = np.zeros(F + L * LF, dtype=np.int64)
+        d[VL["VL_ST_MAGIC"]] = VL["VL_ST_MAGIC_VALUE"]
+        for k, v in (("B", ar.B), ("S", ar.S), ("H", self.H), ("I", self.I), ("NH", self.nh), ("NLAYERS", L)):
+            d[VL["VL_ST_" + k]] = v
+        d[VL["VL_ST_EPS"]] = _f32_bits(self.eps)
+        d[VL["VL_ST_ADDMASK"]] = ar.addmask.data_ptr()
+        if ar.need_grad:
+            d[VL["VL_ST_EV_FORK"]] = ar.fork.cuda_event
+            for k in ("t_dqkv", "t_dt1", "t_du", "t_dt2", "t_x", "t_ctx", "t_x1", "t_h", "cs_qkv", "cs_u"):
+                d[VL["VL_ST_" + k.upper()]] = getattr(ar, k).data_ptr()
+        it = iter(ptrs)
+        for l in range(L):
+            y = F + l * LF
+
+            def put(name, t):
+                d[y + VL["VL_LY_" + name]] = t if isinstance(t, int) else t.data_ptr()
+            put("X32", ar.x32[l % 2]); put("X_LO", ar.x_lo[l % 2])
+            put("X_HI", ar.x_hi[l] if ar.need_grad else ar.x_hi[l % 2])  # per layer when backward needs it, else ping-pong
+            put("OUT32", ar.x32[(l + 1) % 2]); put("OUT_LO", ar.x_lo[(l + 1) % 2])
+            put("OUT_HI", ar.x_hi[l + 1] if ar.need_grad else ar.x_hi[(l + 1) % 2])
+            for k in ("QKV", "O", "W1", "W2"):
+                for suffix in ("_HI", "_LO", "_T"):
+                    put("W" + k + suffix if k in ("QKV", "O") else k + suffix, next(it))
+                put("B" + (k if k in ("QKV", "O") else k[1:]), next(it))
+            for name in ("LN1_G", "LN1_B", "LN2_G", "LN2_B"):
+                put(name, next(it))
+            for i in range(6):
+                d[y + VL["VL_LY_MASK0"] + i] = next(it)
+            for name in ("qkv_hi", "qkv_lo", "ctx_hi", "ctx_lo", "lse", "z1", "mean1", "rstd1", "x1_hi", "u16", "h_hi", "z2",
+                         "mean2", "rstd2"):
+                put(name.upper(), ar.lay(getattr(ar, name), l))
+            put("X1_32", ar.x1_32); put("X1_LO", ar.x1_lo); put("H_LO", ar.h_lo)
+            if ar.need_grad:
+                put("DX", ar.dbuf[l % 2])
+                put("DY", ar.dbuf[(l + 1) % 2])  # (the top layer's DY is patched per backward)
+                put("DZ2", ar.dz2); put("DX1", ar.dx1); put("DZ1", ar.dz1); put("DCTX16", ar.dctx16)
+                for name in ("dt2", "du16", "dt1", "dqkv", "lnws1", "lnws2"):
+                    put(name.upper(), getattr(ar, name)[l])
+        self._desc[id(ar)] = (fp, d)
+        return d
+
+    # ---- forward / backward ----------------------------------------------------------------------------------------
+    def input_buffers(self, ar):
+        """Where the embeddings write the stack's input: (x32, x_hi, x_lo) of layer 0."""
+        return ar.x32[0], ar.x_hi[0], ar.x_lo[0]
+
+    def forward(self, ar, pw_layers, p_hid, p_att, seed0, row_post=None):
+        d = self._descriptor(ar, pw_layers)
+        d[VL["VL_ST_P_HID"]], d[VL["VL_ST_P_ATT"]] = _f32_bits(p_hid), _f32_bits(p_att)
+        d[VL["VL_ST_SEED0"]] = seed0
+        d[VL["VL_ST_ROW_POST"]] = 0 if row_post is None else ar.row_post.data_ptr()
+        d[VL["VL_ST_PROF"]] = 0 if self.prof is None else self.prof.ctypes.data
+        ops.stack_fwd(d, 0, len(self.specs))
+        L = len(self.specs)
+        if ar.need_grad:
+            ar.in_flight = True
+        return ar.x32[L % 2]
+
+    def backward(self, ar, pw_layers, dy, p_hid, p_att, seed0, row_post=None):
+        """dy [M,H] fp32 = dL/d(stack output).  Returns (dL/d(stack input), per-layer grads in LayerSpec.params order:
+        None where the gradient went straight into the optimizer's arena)."""
+        L, dev = len(self.specs), dy.device
+        d = self._descriptor(ar, pw_layers)
+        d[VL["VL_ST_P_HID"]], d[VL["VL_ST_P_ATT"]] = _f32_bits(p_hid), _f32_bits(p_att)
+        d[VL["VL_ST_SEED0"]] = seed0
+        d[VL["VL_ST_ROW_POST"]] = 0 if row_post is None else ar.row_post.data_ptr()
+        d[VL["VL_ST_PROF"]] = 0 if self.prof is None else self.prof.ctypes.data
+        F, LF = VL["VL_ST_FIELDS"], VL["VL_LY_FIELDS"]
+        d[F + (L - 1) * LF + VL["VL_LY_DY"]] = dy.data_ptr()
+        layer_grads, accumulate = [], None
+        use_sink = self.grad_sink is not None and self.layer_done_hook is not None
+        for l, sp in enumerate(self.specs):
+            sink = self.grad_sink(l) if use_sink else None
+            if sink is not None:
+                views, acc = sink
+                layer_grads.append([None] * 16)
+            else:
+                acc = False
+                sizes = [p.numel() for p in sp.params()]
+                flat = torch.empty(sum((n + 3) // 4 * 4 for n in sizes), dtype=torch.float32, device=dev)
+                views, off = [], 0
+                for p_, n in zip(sp.params(), sizes):
+                    views.append(flat[off:off + n].view_as(p_))
+                    off += (n + 3) // 4 * 4
+                layer_grads.append(list(views))
+            if accumulate is None:
+                accumulate = acc
+            elif accumulate != acc:
+                raise RuntimeError("clg_vqa_amd: layers disagree on gradient accumulation")
+            g0 = F + l * LF + VL["VL_LY_GRAD0"]
+            for i, v in enumerate(views):
+                d[g0 + i] = v.data_ptr()
+        d[VL["VL_ST_ACCUMULATE"]] = 1 if accumulate else 0
         main = torch.cuda.current_stream()
         side = None
         if self.overlap_dw:
             if self._side is None or self._side.device != dev:
                 self._side = torch.cuda.Stream(device=dev)
             side = self._side
-        keep = []  # operands of side-stream kernels stay referenced until the streams are joined
-        # one grouped weight-gradient launch per layer needs B*S % 64 == 0 and 8-aligned feature sizes
-        grouped = self.group_dw and M % 64 == 0 and H % 8 == 0 and I % 8 == 0
-        defer_red = side is not None and self.side_reduce
-        pair_red = self.pair_reduce and not defer_red
-        ws_b = ops.ln_bwd_ws(M, H, dev) if pair_red else None  # second workspace: both sets of partials are live
-
-        main_ptr = main.cuda_stream
         side_ptr = side.cuda_stream if side is not None else None
-        if self._fork is None:
-            self._fork = torch.cuda.Event()  # re-recorded for every fork: a wait captures the record enqueued before it
-
-        def on_side(fn, *tensors):
-            """Run fn (weight-gradient work) on the side stream after everything enqueued so far on the main one.
-            torch's current stream stays the main one (no stream context switch: ~30 us each): the launches are routed
-            by handle, results are allocated from the main stream's pool and only consumed after the join, operands
-            and wrapper temporaries stay referenced in `keep` until then."""
-            if side is None:
-                return fn()
-            self._fork.record(main)
-            side.wait_event(self._fork)
-            keep.extend(tensors)
-            ops.set_stream(side_ptr, hold=keep)
-            try:
-                return fn()
-            finally:
-                ops.set_stream(main_ptr)
-
-        def dw_to(dy16, x16, n_out, k_in, views, accumulate, lins):
-            """Weight gradient(s) of the Linear(s) `lins` (packed along the output rows): into the optimizer's arena
-            views when there are any and the shape is on the TN fast path (-> [None, ...]), else as tensors."""
-            n = len(lins)
-            if views is not None and ops.gemm_tn_splitk_to(dy16, x16, n_out, k_in, M, views, accumulate=accumulate):
-                for v, lin in zip(views, lins):
-                    _masked(v, lin)
-                return [None] * n
-            dW = dw_gemm(dy16, x16, M, n_out, k_in)
-            rows = n_out // n
-            return [_masked(dW[i * rows:(i + 1) * rows] if n > 1 else dW, lin) for i, lin in enumerate(lins)]
-
-        for l in reversed(range(len(self.specs))):
-            sp, lw, ls = self.specs[l], pw_layers[l], saved[l]
-            sink = self.grad_sink(l) if (self.grad_sink is not None and self.layer_done_hook is not None) else None
-            sv_, sacc = sink if sink is not None else (None, False)
-            pick = (lambda *idx: [sv_[i] for i in idx]) if sv_ is not None else (lambda *idx: None)  # noqa: E731
-            dz2, dt2 = f32(M, H), b16(M, H)
-            dg2, db2, dbias2 = f32(H), f32(H), f32(H)
-            # the column sums (dgamma, dbeta, the dense layer's bias gradient) are only needed by the optimizer: the
-            # main stream leaves per-workgroup partials (own workspace per call) and the 15-us reduce launch goes to
-            # the weight-gradient stream instead of sitting between the kernels of the critical path
-            ws2 = ops.ln_bwd_ws(M, H, dev) if defer_red else ws
-            if defer_red:
-                ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, None, None,
-                           None, ws2, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
-                on_side(lambda: ops.ln_bwd_reduce(ws2, M, H, dg2, db2, dbias2), ws2)
-            elif pair_red:  # partials only; summed together with the attention sub-layer's LayerNorm below
-                ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, None, None,
-                           None, ws_b, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
-            else:
-                ops.ln_bwd(dy, ls["z2"], ls["mean2"], ls["rstd2"], sp.ln2.weight.detach(), dz2, dt2, None, dg2, db2,
-                           dbias2, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 5), row_post=row_post)
-            du16 = b16(M, I)
-            ops.gemm_nt(dt2, None, lw["w2"].t_hi, None, M, I, H, 1, EPI_DGELU_BF16, out_hi=du16, aux16=ls["u16"])
-            if not grouped:
-                dW2, dW1, dbias1 = on_side(lambda: (dw_to(dt2, ls["h_hi"], H, I, pick(12), sacc, [sp.w2])[0],
-                                                    dw_to(du16, ls["x1_hi"], I, H, pick(10), sacc, [sp.w1])[0],
-                                                    ops.colsum_bf16(du16, M, I, f32(I))),
-                                           dt2, du16, ls["h_hi"], ls["x1_hi"])
-            dx1 = f32(M, H)
-            ops.gemm_nt(du16, None, lw["w1"].t_hi, None, M, H, I, 1, EPI_F32, resid=dz2, out32=dx1)
-            dz1, dt1 = f32(M, H), b16(M, H)
-            dg1, db1, dbias_o = f32(H), f32(H), f32(H)
-            ws1 = ops.ln_bwd_ws(M, H, dev) if defer_red else ws
-            if defer_red:
-                ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, None, None,
-                           None, ws1, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
-                on_side(lambda: ops.ln_bwd_reduce(ws1, M, H, dg1, db1, dbias_o), ws1)
-            elif pair_red:  # one launch sums the partials of both LayerNorms of the layer
-                ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, None, None,
-                           None, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
-                ops.ln_bwd_reduce2(ws_b, M, (dg2, db2, dbias2), ws, M, (dg1, db1, dbias_o), H)
-            else:
-                ops.ln_bwd(dx1, ls["z1"], ls["mean1"], ls["rstd1"], sp.ln1.weight.detach(), dz1, dt1, None, dg1, db1,
-                           dbias_o, ws, M, H, p_pre=p_hid, seed=seed(16 * l + 4))
-            if not grouped:
-                dWo = on_side(lambda: dw_to(dt1, ls["ctx_hi"], H, H, pick(6), sacc, [sp.o])[0], dt1, ls["ctx_hi"])
-            dctx = f32(M, H)
-            ops.gemm_nt(dt1, None, lw["o"].t_hi, None, M, H, H, 1, EPI_F32, out32=dctx)
-            dqkv = b16(M, 3 * H)
-            ops.attn_bwd(ls["qkv32"], am, ls["ctx_hi"], ls["ctx_lo"], dctx, ls["lse"], dqkv, B, S, nh, 64, p_att,
-                         seed(16 * l + 3))
-
-            def qkv_grads():
-                return (dw_to(dqkv, ls["x_hi"], 3 * H, H, pick(0, 2, 4), sacc, [sp.q, sp.k, sp.v]),
-                        ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H)))
-
-            def layer_grads_grouped():
-                # the layer's six weight gradients in ONE launch (no split-K slabs); SFT masks ride in the epilogue
-                dWqkv, dWo, dW1, dW2 = f32(3 * H, H), f32(H, H), f32(I, H), f32(H, I)
-                mk = lambda lin: linear_params(lin)[1]  # noqa: E731
-                probs = [(dqkv[:, i * H:(i + 1) * H], ls["x_hi"], dWqkv[i * H:(i + 1) * H], mk(lin))
-                         for i, lin in enumerate((sp.q, sp.k, sp.v))]
-                probs += [(dt1, ls["ctx_hi"], dWo, mk(sp.o)), (du16, ls["x1_hi"], dW1, mk(sp.w1)),
-                          (dt2, ls["h_hi"], dW2, mk(sp.w2))]
-                ops.gemm_tn_grouped(probs, M)
-                return (dWqkv, ops.colsum_bf16(dqkv, M, 3 * H, f32(3 * H)), dWo, dW1,
-                        ops.colsum_bf16(du16, M, I, f32(I)), dW2)
-
-            if grouped:
-                dWqkv, dbqkv, dWo, dW1, dbias1, dW2 = on_side(layer_grads_grouped, dqkv, dt1, du16, dt2, ls["x_hi"],
-                                                              ls["ctx_hi"], ls["x1_hi"], ls["h_hi"])
-                dWq, dWk, dWv = dWqkv[0:H], dWqkv[H:2 * H], dWqkv[2 * H:]
-            else:
-                (dWq, dWk, dWv), dbqkv = on_side(qkv_grads, dqkv, ls["x_hi"])
-            dx0 = f32(M, H)
-            ops.gemm_nt(dqkv, None, lw["qkv"].t_hi, None, M, H, 3 * H, 1, EPI_F32, resid=dz1, out32=dx0)
-            layer_grads[l] = [dWq, dbqkv[0:H], dWk, dbqkv[H:2 * H], dWv, dbqkv[2 * H:],
-                              dWo, dbias_o, dg1, db1, dW1, dbias1, dW2, dbias2, dg2, db2]
-            if self.layer_done_hook is not None:
-                # multi-GPU: the optimizer takes this layer's gradients now (copy into its flat arena + asynchronous
-                # all-reduce behind the weight-gradient kernels), overlapping the exchange with the rest of backward
-                # (the gradient tensors go into `keep`: the hook's copy kernels read them on the other stream after
-                # this frame has dropped its references)
-                if on_side(lambda: self.layer_done_hook(l, layer_grads[l], side if side is not None else main),
-                           *[g for g in layer_grads[l] if g is not None]):
-                    layer_grads[l] = [None] * len(layer_grads[l])
-            dy = dx0
-            saved[l] = None  # release this layer's activations (side-stream operands stay alive through `keep`)
-        # the join with the weight-gradient stream is left to the caller (TrunkFunction.backward, after the embedding
-        # backward has been enqueued too): the last layer's dW kernels then run under the embedding kernels instead of
-        # stalling the main stream (~0.9 ms of tail per step at c2); `keep` lives until then
-        self._pending = (side, keep) if side is not None else None
-        if self.early_join:
-            self.join()
-        return dy, layer_grads
+        if self.layer_done_hook is None or not use_sink:
+            ops.stack_bwd(d, L, 0, main.cuda_stream, side_ptr)
+        else:
+            # multi-GPU: after each layer's weight-gradient work is enqueued, the optimizer launches that layer's
+            # all-reduce behind it on the same stream, overlapping the exchange with the rest of backward
+            for l in reversed(range(L)):
+                ops.stack_bwd(d, l + 1, l, main.cuda_stream, side_ptr)
+                self.layer_done_hook(l, layer_grads[l], side if side is not None else main)
+        self._pending = side
+        ar.in_flight = False
+        self._keep = layer_grads  # engine-owned gradient buffers are written by the side stream until the join
+        return ar.dbuf[0], layer_grads
 
     def join(self):
-        """Make the current stream wait for the weight-gradient stream; releases the operands kept alive for it."""
+        """Make the current stream wait for the weight-gradient stream."""
         if self._pending is not None:
-            side, _ = self._pending
-            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(self._pending)
             self._pending = None
+        self._keep = None
 
 
 class EngineBase(object):
@@ -387,9 +425,10 @@ class EngineBase(object):
                                       torch.cat([self.pending_word_grad[1], rows]))
 
     def next_seed(self):
+        """(seed0, site -> seed): site s draws from seed0 * 4096 + s (the native stack uses sites 16 l + 3 .. 16 l + 5)."""
         self.calls += 1
         seed0 = (self.base_seed * 0x9E3779B1 + self.calls * 0x10001) & 0x7FFFFFFFFFFF
-        return lambda site: (seed0 * 4096 + site) & 0xFFFFFFFFFFFFFFFF
+        return seed0, (lambda site: (seed0 * 4096 + site) & 0xFFFFFFFFFFFFFFFF)
 
     def prepared(self, device):
         if self._prepared is None or self._prepared["device"] != device:
@@ -452,7 +491,7 @@ class UC2Engine(EngineBase):
         return ps
 
     # ---- forward -------------------------------------------------------------------------------------------------
-    def forward(self, ids, feats, locs, seg, tmask, imask, training):
+    def forward(self, ids, feats, locs, seg, tmask, imask, training, need_grad=True):
         cfg = self.model.config
         emb = self.model.bert.embeddings
         dev = feats.device
@@ -466,7 +505,7 @@ class UC2Engine(EngineBase):
         M, BT, BV = B * S, B * T, B * V
         p_hid = float(cfg.hidden_dropout_prob) if training else 0.0
         p_att = float(cfg.attention_probs_dropout_prob) if training else 0.0
-        seed = self.next_seed()
+        seed0, seed = self.next_seed()
         pw = self.prepared(dev)
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
@@ -474,14 +513,14 @@ class UC2Engine(EngineBase):
         tmask = tmask.contiguous().to(torch.int64); imask = imask.contiguous().to(torch.int64)
         feats2 = feats.contiguous().view(BV, F)
         locs2 = locs.contiguous().view(BV, L)
-        sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, ids=ids, seg=seg,
-                  locs=locs2, pw=pw)
+        ar = self.stack.arena(B, S, dev, need_grad)
+        sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, seed0=seed0, ids=ids, seg=seg,
+                  locs=locs2, pw=pw, arena=ar)
 
-        am = f32(M)
+        am = ar.addmask
         ops.addmask(tmask, imask, am, B, T, V)
-        sv["am"] = am
 
-        x32, x_hi, x_lo = f32(M, H), b16(M, H), b16(M, H)
+        x32, x_hi, x_lo = self.stack.input_buffers(ar)
         # text rows: word + position + type -> LN -> dropout   (embeddings.py:648-655)
         z_t, mean_t, rstd_t = f32(BT, H), f32(BT), f32(BT)
         type_w = emb.new_token_type_embeddings.weight.detach()
@@ -507,8 +546,8 @@ class UC2Engine(EngineBase):
                    seed=seed(2))
         sv.update(z_t=z_t, mean_t=mean_t, rstd_t=rstd_t, f_hi=f_hi, z_i=z_i, mean_i=mean_i, rstd_i=rstd_i,
                   z_l=z_l, mean_l=mean_l, rstd_l=rstd_l, z_v=a32, mean_v=mean_v, rstd_v=rstd_v)
-        x32, x_hi, x_lo, sv["layers"] = self.stack.forward(pw["layers"], x32, x_hi, x_lo, am, B, S, p_hid, p_att, seed)
-        return x32.view(B, S, H), sv
+        out = self.stack.forward(ar, pw["layers"], p_hid, p_att, seed0)
+        return out.view(B, S, H), sv
 
     # ---- backward ------------------------------------------------------------------------------------------------
     def backward(self, sv, dx):
@@ -519,12 +558,12 @@ class UC2Engine(EngineBase):
         H = self.H
         M, BT, BV = B * S, B * T, B * V
         dev = dx.device
-        p_hid, p_att, seed, pw, am = sv["p_hid"], sv["p_att"], sv["seed"], sv["pw"], sv["am"]
+        p_hid, p_att, seed, pw = sv["p_hid"], sv["p_att"], sv["seed"], sv["pw"]
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
         ws = ops.ln_bwd_ws(M, H, dev)
-        dy, layer_grads = self.stack.backward(pw["layers"], sv["layers"], dx.contiguous().view(M, H), am, B, S, p_hid,
-                                              p_att, seed, ws)
+        dy, layer_grads = self.stack.backward(sv["arena"], pw["layers"], dx.contiguous().view(M, H), p_hid, p_att,
+                                              sv["seed0"])
 
         # --- embeddings backward (dy = dL/dX0 [M,H]) ---
         type_w = emb.new_token_type_embeddings.weight
@@ -541,7 +580,7 @@ class UC2Engine(EngineBase):
         dimg16, dg_i, db_i, dbias_img = b16(BV, H), f32(H), f32(H), f32(H)
         ops.ln_bwd(dz_v, sv["z_i"], sv["mean_i"], sv["rstd_i"], emb.image_layer_norm.weight.detach(), None, dimg16,
                    None, dg_i, db_i, dbias_img, ws, BV, H)
-        dWimg = _masked(dw_gemm(dimg16, sv["f_hi"], BV, H, F), emb.image_embeddings)
+        dWimg = dw_gemm(dimg16, sv["f_hi"], BV, H, F, mask=linear_params(emb.image_embeddings)[1])
         dloc32, dg_l, db_l = f32(BV, H), f32(H), f32(H)
         ops.ln_bwd(dz_v, sv["z_l"], sv["mean_l"], sv["rstd_l"], emb.image_location_layer_norm.weight.detach(), None,
                    None, dloc32, dg_l, db_l, None, ws, BV, H)
@@ -571,7 +610,9 @@ class TrunkFunction(torch.autograd.Function):
     def forward(ctx, engine, training, ids, feats, locs, seg, tmask, imask, *params):
         ops.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream lookup for all launches of the pass
         try:
-            out, sv = engine.forward(ids, feats, locs, seg, tmask, imask, training)
+            # (inside autograd.Function.forward grad mode is off: whether a backward can follow is what the inputs say)
+            out, sv = engine.forward(ids, feats, locs, seg, tmask, imask, training,
+                                     need_grad=any(ctx.needs_input_grad))
         finally:
             ops.set_stream(None)
         ctx.engine = engine

@@ -20,7 +20,7 @@ from torch import nn
 from . import ops
 from .config import M3PConfig
 from .encoders import GeLU, PreTrainedModel, SimpleClassifier, VLLinear  # noqa: F401
-from .engine import BF16, EPI_F32, EngineBase, LayerSpec, LayerStack, TrunkFunction, _masked, dw_gemm, linear_params
+from .engine import BF16, EPI_F32, EngineBase, LayerSpec, LayerStack, TrunkFunction, dw_gemm, linear_params
 
 N_MAX_POSITIONS = 514
 
@@ -153,7 +153,7 @@ class M3PEngine(EngineBase):
             ps += sp.params()
         return ps
 
-    def forward(self, ids, feats, locs, seg, tmask, imask, training):
+    def forward(self, ids, feats, locs, seg, tmask, imask, training, need_grad=True):
         c = self.model.config
         e = self.model.bert.encoder
         ie = e.image_embeddings
@@ -166,8 +166,9 @@ class M3PEngine(EngineBase):
         M, BT, BV = B * S, B * T, B * V
         p_hid = float(c.dropout) if training else 0.0
         p_att = float(c.attention_dropout) if training else 0.0
-        seed = self.next_seed()
+        seed0, seed = self.next_seed()
         pw = self.prepared(dev)
+        ar = self.stack.arena(B, S, dev, need_grad)
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
         ids = ids.contiguous()
@@ -177,12 +178,13 @@ class M3PEngine(EngineBase):
         mask = torch.arange(S, device=dev)[None, :] < lens[:, None]
         rowmask = mask.to(torch.float32)
         rm_img, rm_txt = rowmask[:, :V].contiguous().view(BV), rowmask[:, V:].contiguous().view(BT)
-        rowmask = rowmask.contiguous().view(M)
-        am = torch.where(mask, 0.0, float("-inf")).to(torch.float32).contiguous().view(M)
+        ar.row_post.copy_(rowmask.contiguous().view(M))
+        rowmask = ar.row_post
+        ar.addmask.copy_(torch.where(mask, 0.0, float("-inf")).to(torch.float32).contiguous().view(M))
         pos = e.position_embeddings.weight.detach()
         ge, be = e.layer_norm_emb.weight.detach(), e.layer_norm_emb.bias.detach()
 
-        x32, x_hi, x_lo = f32(M, H), b16(M, H), b16(M, H)
+        x32, x_hi, x_lo = self.stack.input_buffers(ar)
         # image rows: dropout(LN(feat W + b + loc W + b)) + pos[v] -> * mask -> layer_norm_emb -> dropout
         f_hi, f_lo = b16(BV, F), b16(BV, F)
         ops.split_f32(feats2, f_hi, f_lo)
@@ -201,12 +203,11 @@ class M3PEngine(EngineBase):
         ops.embed_gather_fwd(ids, e.embeddings.weight.detach(), z_t, BT, H)
         ops.ln_fwd(z_t, None, pos[V:V + T], ge, be, self.eps, x32, x_hi, x_lo, mean_t, rstd_t, BT, H, group=T,
                    out_stride=S, out_off=V, p_post=p_hid, seed=seed(3), row_pre=rm_txt)
-        sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, ids=ids, locs=locs2, pw=pw, am=am,
-                  rowmask=rowmask, rm_img=rm_img, rm_txt=rm_txt, f_hi=f_hi, z1=z_i, mean_i=mean_i, rstd_i=rstd_i,
+        sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, seed0=seed0, ids=ids, locs=locs2, pw=pw,
+                  arena=ar, rowmask=rowmask, rm_img=rm_img, rm_txt=rm_txt, f_hi=f_hi, z1=z_i, mean_i=mean_i, rstd_i=rstd_i,
                   z2=a32, mean_2=mean_2, rstd_2=rstd_2, z_t=z_t, mean_t=mean_t, rstd_t=rstd_t)
-        x32, x_hi, x_lo, sv["layers"] = self.stack.forward(pw["layers"], x32, x_hi, x_lo, am, B, S, p_hid, p_att, seed,
-                                                           row_post=rowmask)
-        return x32.view(B, S, H), sv
+        out = self.stack.forward(ar, pw["layers"], p_hid, p_att, seed0, row_post=rowmask)
+        return out.view(B, S, H), sv
 
     def backward(self, sv, dx):
         c = self.model.config
@@ -216,11 +217,11 @@ class M3PEngine(EngineBase):
         H = self.H
         M, BT, BV = B * S, B * T, B * V
         dev = dx.device
-        p_hid, p_att, seed, pw, am = sv["p_hid"], sv["p_att"], sv["seed"], sv["pw"], sv["am"]
+        p_hid, p_att, seed, pw = sv["p_hid"], sv["p_att"], sv["seed"], sv["pw"]
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         ws = ops.ln_bwd_ws(M, H, dev)
-        dy, layer_grads = self.stack.backward(pw["layers"], sv["layers"], dx.contiguous().view(M, H), am, B, S, p_hid,
-                                              p_att, seed, ws, row_post=sv["rowmask"])
+        dy, layer_grads = self.stack.backward(sv["arena"], pw["layers"], dx.contiguous().view(M, H), p_hid, p_att,
+                                              sv["seed0"], row_post=sv["rowmask"])
         ge = e.layer_norm_emb.weight.detach()
         dpos = torch.zeros_like(e.position_embeddings.weight)
         sink = self.word_grad_sink
@@ -246,7 +247,7 @@ class M3PEngine(EngineBase):
         dg_i, db_i, dbias_img = f32(H), f32(H), f32(H)
         ops.ln_bwd(dz2, sv["z1"], sv["mean_i"], sv["rstd_i"], ie.LayerNorm.weight.detach(), dz1, dimg16, None, dg_i,
                    db_i, dbias_img, ws, BV, H, p_post=p_hid, seed=seed(1))
-        dWimg = _masked(dw_gemm(dimg16, sv["f_hi"], BV, H, F), ie.image_embeddings)
+        dWimg = dw_gemm(dimg16, sv["f_hi"], BV, H, F, mask=linear_params(ie.image_embeddings)[1])
         dWl = torch.zeros_like(ie.image_location_embeddings.weight)
         dbl = torch.zeros_like(ie.image_location_embeddings.bias)
         ops.loc_linear_bwd(sv["locs"], dz1, dWl, dbl, BV, L, H)

@@ -151,6 +151,47 @@ def gemm_tn_grouped(problems, K, splits=0):
                "vl_gemm_tn_grouped")
 
 
+def stack_fwd(desc, layer_begin, layer_end):
+    """desc: numpy int64 descriptor (engine.LayerStack._descriptor)."""
+    _lib.check(_lib.lib().vl_stack_fwd(desc.ctypes.data, layer_begin, layer_end, _stream()), "vl_stack_fwd")
+
+
+def stack_bwd(desc, layer_hi, layer_lo, stream_main, stream_side):
+    _lib.check(_lib.lib().vl_stack_bwd(desc.ctypes.data, layer_hi, layer_lo, stream_main, stream_side), "vl_stack_bwd")
+
+
+def transpose_blocked(entries, M):
+    """entries = [(src [M,N] bf16 (row-major, ld = stride(0)), dst blocked image, colsum_partial or None), ...]"""
+    import ctypes
+    n = len(entries)
+    arr = (ctypes.c_int64 * (6 * n))()
+    for i, (src, dst, cs) in enumerate(entries):
+        ps, ld = _pld(src)
+        arr[6 * i:6 * i + 6] = [ps, ld, src.shape[1], _p(dst), 0 if cs is None else _p(cs), 0]
+    _lib.check(_lib.lib().vl_transpose_blocked(ctypes.cast(arr, ctypes.c_void_p), n, M, _stream()), "vl_transpose_blocked")
+
+
+def colsum_finalize(partial, nblk, N, outs, accumulate=False):
+    import ctypes
+    arr = (ctypes.c_void_p * len(outs))(*[_p(o) for o in outs])
+    _lib.check(_lib.lib().vl_colsum_finalize(_p(partial), nblk, N, ctypes.cast(arr, ctypes.c_void_p), len(outs),
+                                             1 if accumulate else 0, _stream()), "vl_colsum_finalize")
+
+
+def dw_grouped(problems, K, accumulate=False):
+    """problems = [(aT_ptr_tensor, a_row0, a_rows_total, bT_tensor, b_rows_total, out [M,N] fp32, mask or None, M, N)]:
+    aT / bT are blocked images (transpose_blocked); a_row0 selects a row sub-range of the A image."""
+    import ctypes
+    n = len(problems)
+    arr = (ctypes.c_int64 * (10 * n))()
+    for i, (aT, a_row0, a_rows, bT, b_rows, out, mask, M, N) in enumerate(problems):
+        assert out.dtype == torch.float32 and out.stride(1) == 1
+        arr[10 * i:10 * i + 10] = [_p(aT) + 2 * 64 * a_row0, a_rows, _p(bT), b_rows, out.data_ptr(), out.stride(0),
+                                   0 if mask is None else _p(mask), M, N, 0]
+    _lib.check(_lib.lib().vl_dw_grouped(ctypes.cast(arr, ctypes.c_void_p), n, K, 1 if accumulate else 0, _stream()),
+               "vl_dw_grouped")
+
+
 def attn_fwd(qkv32, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed):
     _lib.check(_lib.lib().vl_attn_fwd(_p(qkv32), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
                                       float(p_drop), int(seed), _stream()), "vl_attn_fwd")
@@ -199,11 +240,16 @@ def ln_bwd_reduce(ws, M, H, dgamma, dbeta, dbias):
     _lib.check(_lib.lib().vl_ln_bwd_reduce(_p(ws), M, H, _p(dgamma), _p(dbeta), _p(dbias), _stream()), "vl_ln_bwd_reduce")
 
 
-def ln_bwd_reduce2(ws_a, M_a, outs_a, ws_b, M_b, outs_b, H):
+def ln_bwd_reduce2(ws_a, M_a, outs_a, ws_b, M_b, outs_b, H, accumulate=False):
     """Both column-sum reductions of a transformer layer in one launch; outs = (dgamma, dbeta, dbias)."""
     _lib.check(_lib.lib().vl_ln_bwd_reduce2(_p(ws_a), M_a, _p(outs_a[0]), _p(outs_a[1]), _p(outs_a[2]), _p(ws_b), M_b,
-                                            _p(outs_b[0]), _p(outs_b[1]), _p(outs_b[2]), H, _stream()),
+                                            _p(outs_b[0]), _p(outs_b[1]), _p(outs_b[2]), H, 1 if accumulate else 0,
+                                            _stream()),
                "vl_ln_bwd_reduce2")
+
+
+def memset_zero(t):
+    _lib.check(_lib.lib().vl_memset_zero(_p(t), t.numel() * t.element_size(), _stream()), "vl_memset_zero")
 
 
 def mask_mul(a, m, out):

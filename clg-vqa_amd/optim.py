@@ -263,11 +263,13 @@ class FusedAdamW(object):
         with torch.cuda.stream(stream):  # behind this layer's weight-gradient kernels
             # (None = the GEMM already wrote that gradient into its arena view: the six weight matrices, 99.9 % of
             # the layer's gradient bytes; what is copied here are the ten bias / LayerNorm vectors)
+            # (None = the native stack already wrote that gradient into its arena view -- all 16 of a layer when the
+            # sink is installed; tensors only arrive here from a custom caller)
             dst = [v for g, v in zip(grads, views) if g is not None]
             src = [g.view_as(v) for g, v in zip(grads, views) if g is not None]
-            if again:  # one GPU, gradient accumulation: add to what the earlier backward left in the arena
+            if dst and again:  # one GPU, gradient accumulation: add to what the earlier backward left in the arena
                 torch._foreach_add_(dst, src)
-            else:
+            elif dst:
                 torch._foreach_copy_(dst, src)
             if self.reducer.world_size() > 1:
                 self._works += self.reducer.allreduce_async(self.arena.grad, ranges)

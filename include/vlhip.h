@@ -84,6 +84,28 @@ int vl_gemm_tn_splitk_to(const void* a, int64_t lda, const void* b, int64_t ldb,
 #define VL_TN_FIELDS 10
 int vl_gemm_tn_grouped(const int64_t* probs, int64_t nprob, int64_t K, int64_t splits, void* stream);
 
+/* Weight gradients on K-major operands (csrc/dw.hip).  vl_transpose_blocked re-lays row-major bf16 activations
+ * X [M, N] (ld) as XT[mb][n][mi] = X[64*mb + mi][n] (ceil(M/64) blocks of [N][64]; rows past M are zero; N a multiple of
+ * 64): up to 8 matrices per launch; `tab` is a HOST array of n x VL_TR_FIELDS int64 {src, ld, N, dst, colsum_partial,
+ * 0}; a non-zero colsum_partial ([ceil(M/64), N] floats) receives the per-block column sums of that matrix (the bias
+ * gradient's partial sums, summed by vl_colsum_finalize into 1..4 equal destination segments, e.g. the query / key /
+ * value bias gradients of the packed projection).  vl_blocked_elems(M, N) = elements of one blocked image.
+ * vl_dw_grouped: out_p[M_p, N_p] (+)= A_p^T B_p (* mask_p) for up to 8 problems in ONE launch, A_p^T / B_p^T given as
+ * blocked images (a_rows_total / b_rows_total = N of the image the pointer points into; the pointer may address a row
+ * sub-range, e.g. the key rows of the packed [Q|K|V] gradient): an NT ping-pong product whose K loop runs over the
+ * ceil(K/64) row blocks, accumulated in registers over the whole K range (no split-K slabs, no reduce pass).
+ * `probs`: HOST array of nprob x VL_DW_FIELDS int64 {aT, a_rows_total, bT, b_rows_total, out, ldo, mask (0 = none; fp32,
+ * layout of out), M, N, 0}.  Replaces autograd's grad_weight = grad_output.t() @ input of nn.Linear
+ * (volta/encoders.py:229-246, 411-414, 496-501, 553-556) and, with `mask`, grad(weight_orig) = grad(weight) *
+ * weight_mask of torch.nn.utils.prune under train_task_sft.py:128-132. */
+#define VL_TR_FIELDS 6
+#define VL_DW_FIELDS 10
+int64_t vl_blocked_elems(int64_t M, int64_t N);
+int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, void* stream);
+int vl_colsum_finalize(const float* partial, int64_t nblk, int64_t N, float* const* outs, int64_t nout, int accumulate,
+                       void* stream);
+int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Fused V&L attention core over the single stream X = [text ; boxes]  (S = T + V <= 160, head dim 64).
  * Replaces encoders.py:255-341: four gated score blocks, two concatenated softmaxes, four dropouts, four P.V
@@ -153,7 +175,128 @@ int vl_ln_bwd_reduce(const float* partial_ws, int64_t M, int64_t H, float* dgamm
 /* two independent reductions in one launch (the two LayerNorms of a transformer layer) */
 int vl_ln_bwd_reduce2(const float* ws_a, int64_t M_a, float* dgamma_a, float* dbeta_a, float* dbias_a,
                       const float* ws_b, int64_t M_b, float* dgamma_b, float* dbeta_b, float* dbias_b, int64_t H,
-                      void* stream);
+                      int accumulate, void* stream); /* accumulate != 0: add to the destinations */
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The transformer trunk as ONE call per direction (csrc/stack.hip).  Replaces the Python loop of BertEncoder.forward
+ * (volta/volta/encoders.py:848-892) over 24 sub-layers and autograd's replay of it: the host fills a descriptor (a HOST
+ * array of int64: VL_ST_FIELDS header values, then VL_LY_FIELDS values per layer; pointers are device pointers unless
+ * stated) once per (batch shape, parameter placement) and re-uses it every step.
+ * Header: dims; eps / p_hid / p_att as float BITS; seed0 (site s of layer l draws from seed0*4096 + 16 l + s); addmask
+ * [B*S]; row_post [B*S] or 0 (M3P `tensor *= mask`); EV_FORK = a hipEvent_t of the caller (stream fork, backward);
+ * ACCUMULATE != 0 adds the gradients to their destinations; T_* = blocked K-major images (vl_blocked_elems(B*S, N)
+ * bf16 each) and CS_* = column-sum partials ([ceil(B*S/64), N] fp32), scratch of the weight-gradient stream.
+ * Layer: X32 / X_HI / X_LO = the layer's input (fp32 stream + its split), OUT* = its output (= the next layer's input);
+ * prepared weights W*_HI / W*_LO [N,K], W*_T = transposed hi [K,N], biases, LayerNorm parameters; the activations saved
+ * for backward (QKV_HI/LO [B*S,3H], CTX_HI/LO, LSE, Z1, MEAN1, RSTD1, X1_*, U16, H_HI/LO, Z2, MEAN2, RSTD2); backward
+ * buffers (DY in, DX out, DZ2, DT2, DU16, DX1, DZ1, DT1, DCTX16, DQKV, LayerNorm partial workspaces LNWS1/2 of
+ * vl_ln_bwd_ws_floats(B*S, H) floats each -- DT2 / DU16 / DT1 / DQKV / LNWS* are read by the side stream and must be
+ * private to the layer); GRAD0..GRAD0+15 = gradient destinations in the order {Wq, bq, Wk, bk, Wv, bv, Wo, bo, ln1.g,
+ * ln1.b, W1, b1, W2, b2, ln2.g, ln2.b}; MASK0..MASK0+5 = SFT masks of {Wq, Wk, Wv, Wo, W1, W2} (fp32, 0 = dense).
+ * vl_stack_fwd runs layers [layer_begin, layer_end) on `stream`; vl_stack_bwd runs layers [layer_lo, layer_hi) in
+ * descending order: the critical path on stream_main, the optimizer-only work (K-major re-layout, column sums, grouped
+ * weight-gradient GEMM) forked per layer onto stream_side (NULL = everything on stream_main); the caller joins them.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define VL_ST_MAGIC_VALUE 0x564c5354414b32ll
+enum {
+  VL_ST_MAGIC = 0,
+  VL_ST_B = 1,
+  VL_ST_S = 2,
+  VL_ST_H = 3,
+  VL_ST_I = 4,
+  VL_ST_NH = 5,
+  VL_ST_NLAYERS = 6,
+  VL_ST_EPS = 7,
+  VL_ST_P_HID = 8,
+  VL_ST_P_ATT = 9,
+  VL_ST_SEED0 = 10,
+  VL_ST_ADDMASK = 11,
+  VL_ST_ROW_POST = 12,
+  VL_ST_EV_FORK = 13,
+  VL_ST_ACCUMULATE = 14,
+  VL_ST_T_DQKV = 15,
+  VL_ST_T_DT1 = 16,
+  VL_ST_T_DU = 17,
+  VL_ST_T_DT2 = 18,
+  VL_ST_T_X = 19,
+  VL_ST_T_CTX = 20,
+  VL_ST_T_X1 = 21,
+  VL_ST_T_H = 22,
+  VL_ST_CS_QKV = 23,
+  VL_ST_CS_U = 24,
+  VL_ST_PROF = 25, /* HOST pointer to a VlProf block (0 = no timing), see below */
+  VL_ST_FIELDS = 32
+};
+enum {
+  VL_LY_X32 = 0,
+  VL_LY_X_HI = 1,
+  VL_LY_X_LO = 2,
+  VL_LY_WQKV_HI = 3,
+  VL_LY_WQKV_LO = 4,
+  VL_LY_WQKV_T = 5,
+  VL_LY_BQKV = 6,
+  VL_LY_WO_HI = 7,
+  VL_LY_WO_LO = 8,
+  VL_LY_WO_T = 9,
+  VL_LY_BO = 10,
+  VL_LY_W1_HI = 11,
+  VL_LY_W1_LO = 12,
+  VL_LY_W1_T = 13,
+  VL_LY_B1 = 14,
+  VL_LY_W2_HI = 15,
+  VL_LY_W2_LO = 16,
+  VL_LY_W2_T = 17,
+  VL_LY_B2 = 18,
+  VL_LY_LN1_G = 19,
+  VL_LY_LN1_B = 20,
+  VL_LY_LN2_G = 21,
+  VL_LY_LN2_B = 22,
+  VL_LY_QKV_HI = 23,
+  VL_LY_QKV_LO = 24,
+  VL_LY_CTX_HI = 25,
+  VL_LY_CTX_LO = 26,
+  VL_LY_LSE = 27,
+  VL_LY_Z1 = 28,
+  VL_LY_MEAN1 = 29,
+  VL_LY_RSTD1 = 30,
+  VL_LY_X1_32 = 31,
+  VL_LY_X1_HI = 32,
+  VL_LY_X1_LO = 33,
+  VL_LY_U16 = 34,
+  VL_LY_H_HI = 35,
+  VL_LY_H_LO = 36,
+  VL_LY_Z2 = 37,
+  VL_LY_MEAN2 = 38,
+  VL_LY_RSTD2 = 39,
+  VL_LY_OUT32 = 40,
+  VL_LY_OUT_HI = 41,
+  VL_LY_OUT_LO = 42,
+  VL_LY_DY = 43,
+  VL_LY_DX = 44,
+  VL_LY_DZ2 = 45,
+  VL_LY_DT2 = 46,
+  VL_LY_DU16 = 47,
+  VL_LY_DX1 = 48,
+  VL_LY_DZ1 = 49,
+  VL_LY_DT1 = 50,
+  VL_LY_DCTX16 = 51,
+  VL_LY_DQKV = 52,
+  VL_LY_LNWS1 = 53,
+  VL_LY_LNWS2 = 54,
+  VL_LY_GRAD0 = 55, /* 16 values */
+  VL_LY_MASK0 = 71, /* 6 values */
+  VL_LY_FIELDS = 80
+};
+/* Optional launch timing (benchmarks: roofline numbers measured live, on the stream the kernel runs on).  VL_ST_PROF
+ * points to a HOST int64 block owned by the caller: [0] stride (every stride-th GEMM launch is bracketed), [1] capacity
+ * (event pairs), [2] launch counter, [3] pairs used, then per pair 4 values {event0, event1 (hipEvent_t handles created
+ * by the caller with timing enabled), tag, flops}: the library records the events around the launch and fills tag
+ * (= passes * 16 + epilogue) and flops (2 M N K); the caller reads the elapsed times. */
+#define VL_PROF_HEADER 4
+#define VL_PROF_PAIR 4
+int64_t vl_stack_desc_len(int64_t n_layers);
+int vl_stack_fwd(const int64_t* desc, int64_t layer_begin, int64_t layer_end, void* stream);
+int vl_stack_bwd(const int64_t* desc, int64_t layer_hi, int64_t layer_lo, void* stream_main, void* stream_side);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Sparse fine-tuning mask kernels.
@@ -181,6 +324,7 @@ int vl_imp_select(const float* w, const float* mask, float* new_mask, int64_t n,
 int vl_weight_prep_multi(const int64_t* table_dev, int64_t ndesc, int64_t total_tiles, void* stream);
 
 /* Elementwise / layout helpers. */
+int vl_memset_zero(void* p, int64_t bytes, void* stream); /* zero-fill on the caller's stream */
 int vl_split_f32(const float* x32, void* hi, void* lo, int64_t n, void* stream); /* lo may be NULL (plain cast) */
 int vl_transpose_bf16(const void* in, void* out, int64_t M, int64_t N, int64_t ld_in, int64_t ld_out, void* stream);
 /* out32[n] = sum_m x16[m,n]; ws >= vl_colsum_ws_floats(M,N) floats. */

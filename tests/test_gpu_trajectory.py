@@ -21,7 +21,8 @@ from clg_vqa_amd.synthetic import make_batch, seeded_state_dict  # noqa: E402
 
 # Stated tolerances.  The loss is CE * 1842 (~1.3e4): 1e-3 relative is ~0.1 % of it.  Measured drift is printed.
 LOSS_REL_TOL = 1e-3
-PARAM_REL_L2_TOL = 2e-2   # ||theta_native - theta_oracle|| / ||theta_oracle - theta_0|| per tensor, after N steps
+PARAM_DEV_TOL = 0.5       # ||theta_native - theta_oracle|| / ||theta_oracle - theta_0|| per tensor after N steps (Adam's
+                          # sign-like first updates turn gradient noise on near-zero entries into +-lr steps: reported)
 
 
 @pytest.mark.parametrize("n_layers,n_steps,grad_acc", [(2, 8, 1), (2, 4, 2)])
@@ -70,12 +71,16 @@ def test_training_trajectory_follows_the_fp32_reference(n_layers, n_steps, grad_
     # the loss moved (the comparison is not vacuous) and the parameters followed the same path
     nat = dict(model.named_parameters())
     worst = (0.0, None)
+    devs = []
     for n, p in oracle.named_parameters():
+        if n.endswith("attention_self.key.bias"):
+            continue  # mathematically zero gradient (softmax shift invariance): both runs move it by rounding noise only
         moved = (p.detach() - theta0[n]).double().norm().item()
         if moved == 0.0:
             continue
         d = (nat[n].detach().cpu().double() - p.detach().double()).norm().item() / moved
+        devs.append(d)
         worst = max(worst, (d, n))
-    print("max loss drift %.2e over %d steps; worst parameter deviation relative to the distance travelled: %.3e at %s"
-          % (max(drift), n_steps, worst[0], worst[1]))
-    assert worst[0] <= PARAM_REL_L2_TOL * 50  # reported; see the module docstring -- sign-like Adam updates amplify noise
+    print("max loss drift %.2e over %d steps; parameter deviation relative to the distance travelled: median %.3e, worst "
+          "%.3e at %s" % (max(drift), n_steps, float(np.median(devs)), worst[0], worst[1]))
+    assert worst[0] <= PARAM_DEV_TOL
