@@ -37,13 +37,14 @@ _SIGS = {
     "vl_transpose_blocked": (c_int, [P, c_int64, c_int64, P]),
     "vl_colsum_finalize": (c_int, [P, c_int64, c_int64, P, c_int64, c_int, P]),
     "vl_dw_grouped": (c_int, [P, c_int64, c_int64, c_int, P]),
+    "vl_colreduce_multi": (c_int, [P, c_int64, c_int, P]),
     "vl_attn2_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn2_bwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_ln_fwd": (c_int, [P, P, P, c_int64, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64,
-                          c_int64, c_float, c_float, c_uint64, P]),
+                          c_int64, c_float, c_float, c_uint64, c_int64, c_int64, P]),
     "vl_ln_bwd_ws_floats": (c_int64, [c_int64, c_int64]),
     "vl_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64,
-                          c_float, c_float, c_uint64, P]),
+                          c_float, c_float, c_uint64, c_int64, P]),
     "vl_memset_zero": (c_int, [P, c_int64, P]),
     "vl_mask_mul": (c_int, [P, P, P, c_int64, P]),
     "vl_weight_prep": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),

@@ -119,6 +119,37 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(CsArgs a) {
   }
 }
 
+// Several such column reductions in ONE launch (per layer: the two LayerNorm partial sets -> dgamma, dbeta, bias
+// gradient of the producing Linear; the column-sum partials of dqkv -> bq, bk, bv and of du -> b1): these are ~10-us,
+// latency-bound launches, four of them per layer on the weight-gradient stream otherwise.  256 threads = 64 columns x 4
+// row groups (256-byte contiguous reads per row), fixed summation order (deterministic).
+struct CrSet { const float* src; int nrows; int ncols; int seg; float* out[3]; };
+struct CrArgs { CrSet set[4]; int n; int accumulate; };
+__global__ __launch_bounds__(256) void colreduce_multi_kernel(CrArgs a) {
+  __shared__ float red[4][64];
+  const CrSet& st = a.set[blockIdx.y];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  if (blockIdx.x * 64 >= st.ncols) return;
+  float s0 = 0.f, s1 = 0.f;
+  if (n < st.ncols) {
+    int b = ty;
+    for (; b + 4 < st.nrows; b += 8) {  // two independent chains: more loads in flight
+      s0 += st.src[(long)b * st.ncols + n];
+      s1 += st.src[(long)(b + 4) * st.ncols + n];
+    }
+    for (; b < st.nrows; b += 4) s0 += st.src[(long)b * st.ncols + n];
+  }
+  red[ty][tx] = s0 + s1;
+  __syncthreads();
+  if (ty == 0 && n < st.ncols) {
+    const float t = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    const int seg = n / st.seg;
+    float* o = st.out[seg] + (n - seg * st.seg);
+    if (st.out[seg]) *o = a.accumulate ? *o + t : t;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // grouped NT ping-pong kernel on blocked-transposed operands (structure, hazards and swizzle: gemm.hip gemm3_kernel,
 // configuration 256 x 256, one bf16 pass)
@@ -356,6 +387,27 @@ extern "C" int vl_colsum_finalize(const float* partial, int64_t nblk, int64_t N,
   }
   hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a);
   VL_CHECK_LAUNCH("vl_colsum_finalize");
+  return 0;
+}
+
+// tab: HOST array of n (<= 4) x VL_CR_FIELDS int64 {src, nrows, ncols, seg, out0, out1, out2, 0}: out_t[c] (+)= sum_rows
+// src[row][t * seg + c] (a NULL out_t skips that segment)
+extern "C" int vl_colreduce_multi(const int64_t* tab, int64_t n, int accumulate, void* stream) {
+  VL_CHECK_ARG(tab && n >= 1 && n <= 4, "vl_colreduce_multi: bad arguments");
+  CrArgs a{};
+  a.n = (int)n; a.accumulate = accumulate;
+  int maxc = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t* t = tab + i * VL_CR_FIELDS;
+    CrSet& st = a.set[i];
+    st.src = (const float*)t[0]; st.nrows = (int)t[1]; st.ncols = (int)t[2]; st.seg = (int)t[3];
+    VL_CHECK_ARG(st.src && st.nrows >= 1 && st.ncols >= 1 && st.seg >= 1 && st.ncols % st.seg == 0 && st.ncols / st.seg <= 3,
+                 "vl_colreduce_multi: set %d: bad sizes", i);
+    for (int k = 0; k < 3; ++k) st.out[k] = (float*)t[4 + k];
+    if (st.ncols > maxc) maxc = st.ncols;
+  }
+  hipLaunchKernelGGL(colreduce_multi_kernel, dim3((unsigned)((maxc + 63) / 64), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+  VL_CHECK_LAUNCH("vl_colreduce_multi");
   return 0;
 }
 

@@ -25,6 +25,10 @@ struct LnArgs {
   float* out32; bf16_raw* out_hi; bf16_raw* out_lo; float* mean; float* rstd;
   long M; int H; long group, out_stride, out_off;
   float p_pre, inv_pre, p_post, inv_post; uint64_t seed;
+  // compact-row calls (only a subset of the rows of the full [M_full, H] problem is live, e.g. the pooled row of every
+  // sample in the last layer): row r here is row r * orig_stride of the full problem -- the dropout counter and the
+  // row masks are indexed by that ORIGINAL row (bit-identical to the dense run), resid is read at row r * resid_stride
+  long orig_stride, resid_stride;
   // backward
   const float* dy; const float* z; float* dz; bf16_raw* dpre16; float* dpre32; float* ws; int nblk;
 };
@@ -44,14 +48,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
       const long e = r * p.H + c;
+      const long eo_ = r * p.orig_stride * p.H + c;  // element index in the full problem (dropout counter)
       float4 v = *reinterpret_cast<const float4*>(p.y + e);
       if (p.p_pre > 0.f) {
         float ks_[4];
-        vl_dropout_scale4(p.seed, (uint64_t)e >> 2, p.p_pre, p.inv_pre, ks_);
+        vl_dropout_scale4(p.seed, (uint64_t)eo_ >> 2, p.p_pre, p.inv_pre, ks_);
         v.x *= ks_[0]; v.y *= ks_[1]; v.z *= ks_[2]; v.w *= ks_[3];
       }
       if (p.resid) {
-        const float4 q = *reinterpret_cast<const float4*>(p.resid + e);
+        const float4 q = *reinterpret_cast<const float4*>(p.resid + r * p.resid_stride * p.H + c);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
       if (p.addvec) {
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
       if (p.row_pre) {
-        const float rp = p.row_pre[r];
+        const float rp = p.row_pre[r * p.orig_stride];
         v.x *= rp; v.y *= rp; v.z *= rp; v.w *= rp;
       }
       if (p.p_pre > 0.f || p.resid || p.addvec || p.row_pre) *reinterpret_cast<float4*>(p.y + e) = v;  // z saved in place
@@ -87,13 +92,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
       o.z = g.z * ((z[i].z - mu) * rs) + bt.z;
       o.w = g.w * ((z[i].w - mu) * rs) + bt.w;
       if (p.p_post > 0.f) {
-        const long e = r * p.H + c;
+        const long e = r * p.orig_stride * p.H + c;
         float ks_[4];
         vl_dropout_scale4(p.seed ^ POST_SALT, (uint64_t)e >> 2, p.p_post, p.inv_post, ks_);
         o.x *= ks_[0]; o.y *= ks_[1]; o.z *= ks_[2]; o.w *= ks_[3];
       }
       if (p.row_post) {
-        const float rq = p.row_post[r];
+        const float rq = p.row_post[r * p.orig_stride];
         o.x *= rq; o.y *= rq; o.z *= rq; o.w *= rq;
       }
       const long eo = orow * p.H + c;
@@ -109,6 +114,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
   }
 }
 
+// Backward.  A wave walks TWO rows per trip (rows r and r + rows_per_trip/2): the loads of both are issued before either
+// is reduced, i.e. 12 KB of loads in flight per wave instead of 6 -- the kernel is a latency-bound stream (one dependent
+// load -> two wave reductions -> store chain per row) and was running at 2.8 TB/s with one row per trip.
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
   __shared__ float red[3][4][NV * 256];
@@ -117,64 +125,85 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
   float4 ag[NV], ab[NV], ap[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ap[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (long r = (long)blockIdx.x * 4 + wave; r < p.M; r += (long)gridDim.x * 4) {
-    const long orow = map_row(p, r);
-    const float mu = p.mean[r], rs = p.rstd[r];
-    float4 dy[NV], xh[NV];
-    float s1 = 0.f, s2 = 0.f;
+  const long half = (long)gridDim.x * 4;
+  for (long r0 = (long)blockIdx.x * 4 + wave; r0 < p.M; r0 += 2 * half) {
+    float4 dy[2][NV], zz[2][NV];
+    long rr[2] = {r0, r0 + half};
+    bool ok[2] = {true, r0 + half < p.M};
+    long orow[2];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      const long e = r * p.H + c;
-      float4 d = *reinterpret_cast<const float4*>(p.dy + orow * p.H + c);
-      if (p.p_post > 0.f) {
-        float ks_[4];
-        vl_dropout_scale4(p.seed ^ POST_SALT, (uint64_t)e >> 2, p.p_post, p.inv_post, ks_);
-        d.x *= ks_[0]; d.y *= ks_[1]; d.z *= ks_[2]; d.w *= ks_[3];
+    for (int k = 0; k < 2; ++k) {
+      if (!ok[k]) rr[k] = r0;  // (loads a valid row; its results are discarded)
+      // original (un-compacted) row index: the dropout RNG and the row masks are indexed by it
+      orow[k] = map_row(p, rr[k]);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        dy[k][i] = *reinterpret_cast<const float4*>(p.dy + orow[k] * p.H + c);
+        zz[k][i] = *reinterpret_cast<const float4*>(p.z + rr[k] * p.H + c);
       }
-      if (p.row_post) {
-        const float rq = p.row_post[r];
-        d.x *= rq; d.y *= rq; d.z *= rq; d.w *= rq;
-      }
-      const float4 zz = *reinterpret_cast<const float4*>(p.z + e);
-      const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
-      float4 x;
-      x.x = (zz.x - mu) * rs; x.y = (zz.y - mu) * rs; x.z = (zz.z - mu) * rs; x.w = (zz.w - mu) * rs;
-      ag[i].x += d.x * x.x; ag[i].y += d.y * x.y; ag[i].z += d.z * x.z; ag[i].w += d.w * x.w;
-      ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
-      d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;  // now dL/dxhat
-      s1 += (d.x + d.y) + (d.z + d.w);
-      s2 += (d.x * x.x + d.y * x.y) + (d.z * x.z + d.w * x.w);
-      dy[i] = d; xh[i] = x;
     }
-    const float c1 = wave_sum(s1) * invH, c2 = wave_sum(s2) * invH;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int c = (i * 64 + lane) * 4;
-      const long e = r * p.H + c;
-      float4 dz;
-      dz.x = (dy[i].x - c1 - xh[i].x * c2) * rs;
-      dz.y = (dy[i].y - c1 - xh[i].y * c2) * rs;
-      dz.z = (dy[i].z - c1 - xh[i].z * c2) * rs;
-      dz.w = (dy[i].w - c1 - xh[i].w * c2) * rs;
-      if (p.row_pre) {
-        const float rp = p.row_pre[r];
-        dz.x *= rp; dz.y *= rp; dz.z *= rp; dz.w *= rp;
+    for (int k = 0; k < 2; ++k) {
+      if (!ok[k]) continue;
+      const long r = rr[k];
+      const float mu = p.mean[r], rs = p.rstd[r];
+      float4 xh[NV];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const long e = r * p.orig_stride * p.H + c;
+        float4 d = dy[k][i];
+        if (p.p_post > 0.f) {
+          float ks_[4];
+          vl_dropout_scale4(p.seed ^ POST_SALT, (uint64_t)e >> 2, p.p_post, p.inv_post, ks_);
+          d.x *= ks_[0]; d.y *= ks_[1]; d.z *= ks_[2]; d.w *= ks_[3];
+        }
+        if (p.row_post) {
+          const float rq = p.row_post[r * p.orig_stride];
+          d.x *= rq; d.y *= rq; d.z *= rq; d.w *= rq;
+        }
+        const float4 z = zz[k][i];
+        const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
+        float4 x;
+        x.x = (z.x - mu) * rs; x.y = (z.y - mu) * rs; x.z = (z.z - mu) * rs; x.w = (z.w - mu) * rs;
+        ag[i].x += d.x * x.x; ag[i].y += d.y * x.y; ag[i].z += d.z * x.z; ag[i].w += d.w * x.w;
+        ab[i].x += d.x; ab[i].y += d.y; ab[i].z += d.z; ab[i].w += d.w;
+        d.x *= g.x; d.y *= g.y; d.z *= g.z; d.w *= g.w;  // now dL/dxhat
+        s1 += (d.x + d.y) + (d.z + d.w);
+        s2 += (d.x * x.x + d.y * x.y) + (d.z * x.z + d.w * x.w);
+        dy[k][i] = d; xh[i] = x;
       }
-      if (p.dz) *reinterpret_cast<float4*>(p.dz + e) = dz;
-      float4 dp = dz;
-      if (p.p_pre > 0.f) {
-        float ks_[4];
-        vl_dropout_scale4(p.seed, (uint64_t)e >> 2, p.p_pre, p.inv_pre, ks_);
-        dp.x *= ks_[0]; dp.y *= ks_[1]; dp.z *= ks_[2]; dp.w *= ks_[3];
+      const float c1 = wave_sum(s1) * invH, c2 = wave_sum(s2) * invH;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        const long e = r * p.H + c;
+        float4 dz;
+        dz.x = (dy[k][i].x - c1 - xh[i].x * c2) * rs;
+        dz.y = (dy[k][i].y - c1 - xh[i].y * c2) * rs;
+        dz.z = (dy[k][i].z - c1 - xh[i].z * c2) * rs;
+        dz.w = (dy[k][i].w - c1 - xh[i].w * c2) * rs;
+        if (p.row_pre) {
+          const float rp = p.row_pre[r * p.orig_stride];
+          dz.x *= rp; dz.y *= rp; dz.z *= rp; dz.w *= rp;
+        }
+        if (p.dz) *reinterpret_cast<float4*>(p.dz + e) = dz;
+        float4 dp = dz;
+        if (p.p_pre > 0.f) {
+          float ks_[4];
+          vl_dropout_scale4(p.seed, (uint64_t)(r * p.orig_stride * p.H + c) >> 2, p.p_pre, p.inv_pre, ks_);
+          dp.x *= ks_[0]; dp.y *= ks_[1]; dp.z *= ks_[2]; dp.w *= ks_[3];
+        }
+        if (p.dpre32) *reinterpret_cast<float4*>(p.dpre32 + e) = dp;
+        if (p.dpre16) {
+          ushort4 h;
+          h.x = f32_to_bf16(dp.x); h.y = f32_to_bf16(dp.y); h.z = f32_to_bf16(dp.z); h.w = f32_to_bf16(dp.w);
+          *reinterpret_cast<ushort4*>(p.dpre16 + e) = h;
+        }
+        ap[i].x += dp.x; ap[i].y += dp.y; ap[i].z += dp.z; ap[i].w += dp.w;
       }
-      if (p.dpre32) *reinterpret_cast<float4*>(p.dpre32 + e) = dp;
-      if (p.dpre16) {
-        ushort4 h;
-        h.x = f32_to_bf16(dp.x); h.y = f32_to_bf16(dp.y); h.z = f32_to_bf16(dp.z); h.w = f32_to_bf16(dp.w);
-        *reinterpret_cast<ushort4*>(p.dpre16 + e) = h;
-      }
-      ap[i].x += dp.x; ap[i].y += dp.y; ap[i].z += dp.z; ap[i].w += dp.w;
     }
   }
   // combine the 4 waves' column partials, then one partial row-set per workgroup
@@ -259,7 +288,8 @@ int check_shape(const char* fn, int64_t M, int64_t H, int64_t group, float p_pre
 extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, int64_t addvec_rows,
                          const float* row_pre, const float* row_post, const float* gamma, const float* beta, float eps, float* out32, void* out_hi, void* out_lo, float* mean,
                          float* rstd, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
-                         float p_pre, float p_post, uint64_t seed, void* stream) {
+                         float p_pre, float p_post, uint64_t seed, int64_t orig_row_stride, int64_t resid_row_stride,
+                         void* stream) {
   if (int rc = check_shape("vl_ln_fwd", M, H, group, p_pre, p_post)) return rc;
   VL_CHECK_ARG(y32_z32 && gamma && beta && mean && rstd && (out32 || out_hi), "vl_ln_fwd: null pointer");
   LnArgs a{};
@@ -270,6 +300,8 @@ extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addv
   a.M = M; a.H = (int)H; a.group = group; a.out_stride = out_stride; a.out_off = out_off;
   a.p_pre = p_pre; a.inv_pre = 1.f / (1.f - p_pre); a.p_post = p_post; a.inv_post = 1.f / (1.f - p_post);
   a.seed = seed;
+  VL_CHECK_ARG(orig_row_stride >= 1 && resid_row_stride >= 1, "vl_ln_fwd: row strides must be >= 1");
+  a.orig_stride = orig_row_stride; a.resid_stride = resid_row_stride;
   hipStream_t s = (hipStream_t)stream;
   switch (H / 256) {
     case 1: return launch_fwd<1>(a, s);
@@ -287,8 +319,9 @@ extern "C" int vl_ln_debug_blocks(int n) { if (n >= 64 && n <= 8192) g_ln_bwd_bl
 extern "C" int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd,
                          const float* gamma, const float* row_pre, const float* row_post, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta,
                          float* dbias, float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride,
-                         int64_t out_off, float p_pre, float p_post, uint64_t seed, void* stream) {
+                         int64_t out_off, float p_pre, float p_post, uint64_t seed, int64_t orig_row_stride, void* stream) {
   if (int rc = check_shape("vl_ln_bwd", M, H, group, p_pre, p_post)) return rc;
+  VL_CHECK_ARG(orig_row_stride >= 1, "vl_ln_bwd: orig_row_stride must be >= 1");
   VL_CHECK_ARG(dy32 && z32 && mean && rstd && gamma && partial_ws, "vl_ln_bwd: null pointer");
   LnArgs a{};
   a.dy = dy32; a.z = z32; a.mean = const_cast<float*>(mean); a.rstd = const_cast<float*>(rstd); a.gamma = gamma;
@@ -297,6 +330,7 @@ extern "C" int vl_ln_bwd(const float* dy32, const float* z32, const float* mean,
   a.M = M; a.H = (int)H; a.group = group; a.out_stride = out_stride; a.out_off = out_off;
   a.p_pre = p_pre; a.inv_pre = 1.f / (1.f - p_pre); a.p_post = p_post; a.inv_post = 1.f / (1.f - p_post);
   a.seed = seed;
+  a.orig_stride = orig_row_stride; a.resid_stride = 1;
   hipStream_t s = (hipStream_t)stream;
   switch (H / 256) {
     case 1: return launch_bwd<1>(a, s, dgamma, dbeta, dbias);

@@ -77,29 +77,34 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
   for (int64_t l = layer_begin; l < layer_end; ++l) {
     const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
     const int s3 = (int)(16 * l + 3);
+    // only the pooled row of every sample leaves the LAST layer (BertTextPooler reads hidden_states[:, 0],
+    // encoders.py:597-608; M3P's BertPooler likewise): everything after the K/V projection of that layer runs on the
+    // B live rows (R), in compact [B, .] buffers, with the dropout counters / row masks of the original rows (stride S)
+    const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;
+    const int64_t R = pooled ? B : M, nq = pooled ? 1 : S, os = pooled ? S : 1;
     // Q | K | V = X W^T + b, written as the (hi, lo) split the attention kernel reads
     VL_TRY(gemm(prof, ptr<void>(y[VL_LY_X_HI]), ptr<void>(y[VL_LY_X_LO]), H, ptr<void>(y[VL_LY_WQKV_HI]), ptr<void>(y[VL_LY_WQKV_LO]), H,
-                      M, 3 * H, H, 3, VL_EPI_SPLIT, ptr<const float>(y[VL_LY_BQKV]), nullptr, nullptr, 0,
-                      ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), nullptr, 3 * H, stream));
+                M, 3 * H, H, 3, VL_EPI_SPLIT, ptr<const float>(y[VL_LY_BQKV]), nullptr, nullptr, 0,
+                ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), nullptr, 3 * H, stream));
     VL_TRY(vl_attn2_fwd(ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), addmask, ptr<void>(y[VL_LY_CTX_HI]),
-                        ptr<void>(y[VL_LY_CTX_LO]), ptr<float>(y[VL_LY_LSE]), B, S, nh, 64, S, p_att, seed_of(d[VL_ST_SEED0], s3), stream));
+                        ptr<void>(y[VL_LY_CTX_LO]), ptr<float>(y[VL_LY_LSE]), B, S, nh, 64, nq, p_att, seed_of(d[VL_ST_SEED0], s3), stream));
     VL_TRY(gemm(prof, ptr<void>(y[VL_LY_CTX_HI]), ptr<void>(y[VL_LY_CTX_LO]), H, ptr<void>(y[VL_LY_WO_HI]), ptr<void>(y[VL_LY_WO_LO]), H,
-                      M, H, H, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_BO]), nullptr, ptr<float>(y[VL_LY_Z1]), H, nullptr, nullptr,
-                      nullptr, 0, stream));
+                R, H, H, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_BO]), nullptr, ptr<float>(y[VL_LY_Z1]), H, nullptr, nullptr,
+                nullptr, 0, stream));
     VL_TRY(vl_ln_fwd(ptr<float>(y[VL_LY_Z1]), ptr<const float>(y[VL_LY_X32]), nullptr, 1, nullptr, nullptr,
                      ptr<const float>(y[VL_LY_LN1_G]), ptr<const float>(y[VL_LY_LN1_B]), eps, ptr<float>(y[VL_LY_X1_32]),
                      ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), ptr<float>(y[VL_LY_MEAN1]), ptr<float>(y[VL_LY_RSTD1]),
-                     M, H, M, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 1), stream));
+                     R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 1), os, os, stream));
     VL_TRY(gemm(prof, ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), H, ptr<void>(y[VL_LY_W1_HI]), ptr<void>(y[VL_LY_W1_LO]), H,
-                      M, I, H, 3, VL_EPI_GELU_SPLIT, ptr<const float>(y[VL_LY_B1]), nullptr, nullptr, 0, ptr<void>(y[VL_LY_H_HI]),
-                      ptr<void>(y[VL_LY_H_LO]), ptr<void>(y[VL_LY_U16]), I, stream));
+                R, I, H, 3, VL_EPI_GELU_SPLIT, ptr<const float>(y[VL_LY_B1]), nullptr, nullptr, 0, ptr<void>(y[VL_LY_H_HI]),
+                ptr<void>(y[VL_LY_H_LO]), ptr<void>(y[VL_LY_U16]), I, stream));
     VL_TRY(gemm(prof, ptr<void>(y[VL_LY_H_HI]), ptr<void>(y[VL_LY_H_LO]), I, ptr<void>(y[VL_LY_W2_HI]), ptr<void>(y[VL_LY_W2_LO]), I,
-                      M, H, I, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_B2]), nullptr, ptr<float>(y[VL_LY_Z2]), H, nullptr, nullptr,
-                      nullptr, 0, stream));
+                R, H, I, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_B2]), nullptr, ptr<float>(y[VL_LY_Z2]), H, nullptr, nullptr,
+                nullptr, 0, stream));
     VL_TRY(vl_ln_fwd(ptr<float>(y[VL_LY_Z2]), ptr<const float>(y[VL_LY_X1_32]), nullptr, 1, nullptr, row_post,
                      ptr<const float>(y[VL_LY_LN2_G]), ptr<const float>(y[VL_LY_LN2_B]), eps, ptr<float>(y[VL_LY_OUT32]),
                      ptr<void>(y[VL_LY_OUT_HI]), ptr<void>(y[VL_LY_OUT_LO]), ptr<float>(y[VL_LY_MEAN2]), ptr<float>(y[VL_LY_RSTD2]),
-                     M, H, M, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 2), stream));
+                     R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 2), os, 1, stream));
   }
   return 0;
 }
@@ -120,54 +125,68 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
   hipStream_t ss = stream_side ? (hipStream_t)stream_side : sm;
   hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);
   VL_CHECK_ARG(ss == sm || fork, "vl_stack_bwd: a side stream needs the fork event of the descriptor");
-  const int64_t mblk = (M + 63) / 64;
   for (int64_t l = layer_hi - 1; l >= layer_lo; --l) {
     const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
     const int s3 = (int)(16 * l + 3);
+    const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;  // see vl_stack_fwd: DY is the compact [B, H] gradient
+    const int64_t R = pooled ? B : M, nq = pooled ? 1 : S, os = pooled ? S : 1;
+    VL_CHECK_ARG(!pooled || d[VL_ST_ROWS0], "vl_stack_bwd: the pooled-row mode needs VL_ST_ROWS0");
     // ---- critical path ------------------------------------------------------------------------------------------
     VL_TRY(vl_ln_bwd(ptr<const float>(y[VL_LY_DY]), ptr<const float>(y[VL_LY_Z2]), ptr<const float>(y[VL_LY_MEAN2]),
                      ptr<const float>(y[VL_LY_RSTD2]), ptr<const float>(y[VL_LY_LN2_G]), nullptr, row_post, ptr<float>(y[VL_LY_DZ2]),
-                     ptr<void>(y[VL_LY_DT2]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS2]), M, H, M, 0, 0, p_hid, 0.f,
-                     seed_of(d[VL_ST_SEED0], s3 + 2), sm));
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT2]), nullptr, H, ptr<void>(y[VL_LY_W2_T]), nullptr, H, M, I, H, 1, VL_EPI_DGELU_BF16,
-                      nullptr, nullptr, nullptr, 0, ptr<void>(y[VL_LY_DU16]), nullptr, ptr<void>(y[VL_LY_U16]), I, sm));
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DU16]), nullptr, I, ptr<void>(y[VL_LY_W1_T]), nullptr, I, M, H, I, 1, VL_EPI_F32, nullptr,
-                      ptr<const float>(y[VL_LY_DZ2]), ptr<float>(y[VL_LY_DX1]), H, nullptr, nullptr, nullptr, 0, sm));
+                     ptr<void>(y[VL_LY_DT2]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS2]), R, H, R, 0, 0, p_hid, 0.f,
+                     seed_of(d[VL_ST_SEED0], s3 + 2), os, sm));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT2]), nullptr, H, ptr<void>(y[VL_LY_W2_T]), nullptr, H, R, I, H, 1, VL_EPI_DGELU_BF16,
+                nullptr, nullptr, nullptr, 0, ptr<void>(y[VL_LY_DU16]), nullptr, ptr<void>(y[VL_LY_U16]), I, sm));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DU16]), nullptr, I, ptr<void>(y[VL_LY_W1_T]), nullptr, I, R, H, I, 1, VL_EPI_F32, nullptr,
+                ptr<const float>(y[VL_LY_DZ2]), ptr<float>(y[VL_LY_DX1]), H, nullptr, nullptr, nullptr, 0, sm));
     VL_TRY(vl_ln_bwd(ptr<const float>(y[VL_LY_DX1]), ptr<const float>(y[VL_LY_Z1]), ptr<const float>(y[VL_LY_MEAN1]),
                      ptr<const float>(y[VL_LY_RSTD1]), ptr<const float>(y[VL_LY_LN1_G]), nullptr, nullptr, ptr<float>(y[VL_LY_DZ1]),
-                     ptr<void>(y[VL_LY_DT1]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS1]), M, H, M, 0, 0, p_hid, 0.f,
-                     seed_of(d[VL_ST_SEED0], s3 + 1), sm));
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT1]), nullptr, H, ptr<void>(y[VL_LY_WO_T]), nullptr, H, M, H, H, 1, VL_EPI_BF16, nullptr,
-                      nullptr, nullptr, 0, ptr<void>(y[VL_LY_DCTX16]), nullptr, nullptr, H, sm));
+                     ptr<void>(y[VL_LY_DT1]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS1]), R, H, R, 0, 0, p_hid, 0.f,
+                     seed_of(d[VL_ST_SEED0], s3 + 1), os, sm));
+    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT1]), nullptr, H, ptr<void>(y[VL_LY_WO_T]), nullptr, H, R, H, H, 1, VL_EPI_BF16, nullptr,
+                nullptr, nullptr, 0, ptr<void>(y[VL_LY_DCTX16]), nullptr, nullptr, H, sm));
     VL_TRY(vl_attn2_bwd(ptr<void>(y[VL_LY_QKV_HI]), addmask, ptr<void>(y[VL_LY_DCTX16]), ptr<const float>(y[VL_LY_LSE]),
-                        ptr<void>(y[VL_LY_DQKV]), B, S, nh, 64, S, p_att, seed_of(d[VL_ST_SEED0], s3), sm));
+                        ptr<void>(y[VL_LY_DQKV]), B, S, nh, 64, nq, p_att, seed_of(d[VL_ST_SEED0], s3), sm));
     if (ss != sm) {  // everything the side stream reads of this layer has been enqueued on the main stream
       hipError_t e = hipEventRecord(fork, sm);
       if (e == hipSuccess) e = hipStreamWaitEvent(ss, fork, 0);
       if (e != hipSuccess) return vl_set_error(-3, "vl_stack_bwd: stream fork: %s", hipGetErrorString(e));
     }
+    // dL/dX = dQKV W_qkv + dz1 (the residual branch); in the pooled-row mode dz1 only has the B live rows: they are
+    // added to rows b * S afterwards (one fp32 add per element either way: bit-identical to the dense epilogue)
     VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DQKV]), nullptr, 3 * H, ptr<void>(y[VL_LY_WQKV_T]), nullptr, 3 * H, M, H, 3 * H, 1, VL_EPI_F32,
-                      nullptr, ptr<const float>(y[VL_LY_DZ1]), ptr<float>(y[VL_LY_DX]), H, nullptr, nullptr, nullptr, 0, sm));
+                nullptr, pooled ? nullptr : ptr<const float>(y[VL_LY_DZ1]), ptr<float>(y[VL_LY_DX]), H, nullptr, nullptr, nullptr, 0,
+                sm));
+    if (pooled)
+      VL_TRY(vl_embed_scatter_add(ptr<const int64_t>(d[VL_ST_ROWS0]), ptr<const float>(y[VL_LY_DZ1]), ptr<float>(y[VL_LY_DX]), B, H,
+                                  -1, nullptr, sm));
     // ---- optimizer-only work: K-major re-layout, column sums, grouped weight-gradient GEMM ---------------------------
+    const int64_t mblk = (M + 63) / 64, rblk = (R + 63) / 64;
     const int64_t tr[8 * VL_TR_FIELDS] = {
         y[VL_LY_DQKV], 3 * H, 3 * H, d[VL_ST_T_DQKV], d[VL_ST_CS_QKV], 0,
+        y[VL_LY_X_HI], H, H, d[VL_ST_T_X], 0, 0,
         y[VL_LY_DT1], H, H, d[VL_ST_T_DT1], 0, 0,
         y[VL_LY_DU16], I, I, d[VL_ST_T_DU], d[VL_ST_CS_U], 0,
         y[VL_LY_DT2], H, H, d[VL_ST_T_DT2], 0, 0,
-        y[VL_LY_X_HI], H, H, d[VL_ST_T_X], 0, 0,
         y[VL_LY_CTX_HI], H, H, d[VL_ST_T_CTX], 0, 0,
         y[VL_LY_X1_HI], H, H, d[VL_ST_T_X1], 0, 0,
         y[VL_LY_H_HI], I, I, d[VL_ST_T_H], 0, 0};
-    VL_TRY(vl_transpose_blocked(tr, 8, M, ss));
-    float* const* g = reinterpret_cast<float* const*>(y + VL_LY_GRAD0);  // 16 destinations, LayerSpec.params order
-    float* bq[3] = {ptr<float>(y[VL_LY_GRAD0 + 1]), ptr<float>(y[VL_LY_GRAD0 + 3]), ptr<float>(y[VL_LY_GRAD0 + 5])};
-    float* b1[1] = {ptr<float>(y[VL_LY_GRAD0 + 11])};
-    (void)g;
-    VL_TRY(vl_colsum_finalize(ptr<const float>(d[VL_ST_CS_QKV]), mblk, 3 * H, bq, 3, accumulate, ss));
-    VL_TRY(vl_colsum_finalize(ptr<const float>(d[VL_ST_CS_U]), mblk, I, b1, 1, accumulate, ss));
-    VL_TRY(vl_ln_bwd_reduce2(ptr<const float>(y[VL_LY_LNWS2]), M, ptr<float>(y[VL_LY_GRAD0 + 14]), ptr<float>(y[VL_LY_GRAD0 + 15]),
-                             ptr<float>(y[VL_LY_GRAD0 + 13]), ptr<const float>(y[VL_LY_LNWS1]), M, ptr<float>(y[VL_LY_GRAD0 + 8]),
-                             ptr<float>(y[VL_LY_GRAD0 + 9]), ptr<float>(y[VL_LY_GRAD0 + 7]), H, accumulate, ss));
+    if (pooled) {  // the first two operands have M rows, the other six only the B live ones
+      VL_TRY(vl_transpose_blocked(tr, 2, M, ss));
+      VL_TRY(vl_transpose_blocked(tr + 2 * VL_TR_FIELDS, 6, R, ss));
+    } else {
+      VL_TRY(vl_transpose_blocked(tr, 8, M, ss));
+    }
+    // one launch: LayerNorm partials -> (dgamma, dbeta, bias gradient of the producing Linear) x 2, column-sum partials
+    // of dqkv -> (bq, bk, bv) and of du -> b1
+    const int64_t nws = vl_ln_bwd_ws_floats(R, H) / (3 * H);
+    const int64_t cr[4 * VL_CR_FIELDS] = {
+        y[VL_LY_LNWS2], nws, 3 * H, H, y[VL_LY_GRAD0 + 14], y[VL_LY_GRAD0 + 15], y[VL_LY_GRAD0 + 13], 0,
+        y[VL_LY_LNWS1], nws, 3 * H, H, y[VL_LY_GRAD0 + 8], y[VL_LY_GRAD0 + 9], y[VL_LY_GRAD0 + 7], 0,
+        d[VL_ST_CS_QKV], mblk, 3 * H, H, y[VL_LY_GRAD0 + 1], y[VL_LY_GRAD0 + 3], y[VL_LY_GRAD0 + 5], 0,
+        d[VL_ST_CS_U], rblk, I, I, y[VL_LY_GRAD0 + 11], 0, 0, 0};
+    VL_TRY(vl_colreduce_multi(cr, 4, accumulate, ss));
     const int64_t pr[6 * VL_DW_FIELDS] = {
         d[VL_ST_T_DQKV], 3 * H, d[VL_ST_T_X], H, y[VL_LY_GRAD0 + 0], H, y[VL_LY_MASK0 + 0], H, H, 0,
         d[VL_ST_T_DQKV] + 2 * 64 * H, 3 * H, d[VL_ST_T_X], H, y[VL_LY_GRAD0 + 2], H, y[VL_LY_MASK0 + 1], H, H, 0,
@@ -175,7 +194,12 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
         d[VL_ST_T_DT1], H, d[VL_ST_T_CTX], H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
         d[VL_ST_T_DU], I, d[VL_ST_T_X1], H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, 0,
         d[VL_ST_T_DT2], H, d[VL_ST_T_H], I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
-    VL_TRY(vl_dw_grouped(pr, 6, M, accumulate, ss));
+    if (pooled) {  // Q/K/V gradients reduce over all M rows, the other three over the B live rows
+      VL_TRY(vl_dw_grouped(pr, 3, M, accumulate, ss));
+      VL_TRY(vl_dw_grouped(pr + 3 * VL_DW_FIELDS, 3, R, accumulate, ss));
+    } else {
+      VL_TRY(vl_dw_grouped(pr, 6, M, accumulate, ss));
+    }
   }
   return 0;
 }

@@ -194,6 +194,7 @@ class StackArena(object):
         self.u16, self.h_hi, self.h_lo = b16(n, M, I), b16(n, M, I), b16(M, I)
         self.z2, self.mean2, self.rstd2 = f32(n, M, H), f32(n, M), f32(n, M)
         self.addmask, self.row_post = f32(M), f32(M)
+        self.rows0 = torch.arange(B, dtype=torch.int64, device=device) * S  # the pooled row of every sample
         self.in_flight = False  # a training forward whose backward has not run yet owns the saved activations
         if need_grad:
             lib = _lib.lib()
@@ -222,6 +223,10 @@ class LayerStack(object):
     def __init__(self, specs, H, nh, I, eps):
         self.specs, self.H, self.nh, self.I, self.eps = specs, H, nh, I, eps
         self.overlap_dw = True   # weight-gradient work on a second HIP stream (A/B knob)
+        # the heads of this path read hidden_states[:, 0] only (BertTextPooler encoders.py:597-608, M3P BertPooler): the
+        # last layer then runs on the B live rows after its K/V projection and the stack returns [B, 1, H] (exact: the
+        # live rows are bit-identical to the dense run, the dead ones are never computed)
+        self.pooled_only = True
         self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
         # callable(layer) -> (16 destination views in LayerSpec.params order, accumulate) or None: when the optimizer
         # provides it, gradients are written straight into its flat arena
@@ -272,6 +277,7 @@ class LayerStack(object):
             d[VL["VL_ST_" + k]] = v
         d[VL["VL_ST_EPS"]] = _f32_bits(self.eps)
         d[VL["VL_ST_ADDMASK"]] = ar.addmask.data_ptr()
+        d[VL["VL_ST_ROWS0"]] = ar.rows0.data_ptr()
         if ar.need_grad:
             d[VL["VL_ST_EV_FORK"]] = ar.fork.cuda_event
             for k in ("t_dqkv", "t_dt1", "t_du", "t_dt2", "t_x", "t_ctx", "t_x1", "t_h", "cs_qkv", "cs_u"):
@@ -318,11 +324,15 @@ class LayerStack(object):
         d[VL["VL_ST_SEED0"]] = seed0
         d[VL["VL_ST_ROW_POST"]] = 0 if row_post is None else ar.row_post.data_ptr()
         d[VL["VL_ST_PROF"]] = 0 if self.prof is None else self.prof.ctypes.data
+        d[VL["VL_ST_POOLED_ONLY"]] = 1 if self.pooled_only else 0
         ops.stack_fwd(d, 0, len(self.specs))
         L = len(self.specs)
         if ar.need_grad:
             ar.in_flight = True
-        return ar.x32[L % 2]
+        ar.pooled = self.pooled_only
+        out = ar.x32[L % 2]
+        H = self.H
+        return out[:ar.B].view(ar.B, 1, H) if self.pooled_only else out.view(ar.B, ar.S, H)
 
     def backward(self, ar, pw_layers, dy, p_hid, p_att, seed0, row_post=None):
         """dy [M,H] fp32 = dL/d(stack output).  Returns (dL/d(stack input), per-layer grads in LayerSpec.params order:
@@ -333,6 +343,8 @@ class LayerStack(object):
         d[VL["VL_ST_SEED0"]] = seed0
         d[VL["VL_ST_ROW_POST"]] = 0 if row_post is None else ar.row_post.data_ptr()
         d[VL["VL_ST_PROF"]] = 0 if self.prof is None else self.prof.ctypes.data
+        d[VL["VL_ST_POOLED_ONLY"]] = 1 if ar.pooled else 0
+        assert dy.numel() == (ar.B if ar.pooled else ar.B * ar.S) * self.H
         F, LF = VL["VL_ST_FIELDS"], VL["VL_LY_FIELDS"]
         d[F + (L - 1) * LF + VL["VL_LY_DY"]] = dy.data_ptr()
         layer_grads, accumulate = [], None
@@ -546,8 +558,7 @@ class UC2Engine(EngineBase):
                    seed=seed(2))
         sv.update(z_t=z_t, mean_t=mean_t, rstd_t=rstd_t, f_hi=f_hi, z_i=z_i, mean_i=mean_i, rstd_i=rstd_i,
                   z_l=z_l, mean_l=mean_l, rstd_l=rstd_l, z_v=a32, mean_v=mean_v, rstd_v=rstd_v)
-        out = self.stack.forward(ar, pw["layers"], p_hid, p_att, seed0)
-        return out.view(B, S, H), sv
+        return self.stack.forward(ar, pw["layers"], p_hid, p_att, seed0), sv
 
     # ---- backward ------------------------------------------------------------------------------------------------
     def backward(self, sv, dx):
@@ -562,7 +573,7 @@ class UC2Engine(EngineBase):
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
         ws = ops.ln_bwd_ws(M, H, dev)
-        dy, layer_grads = self.stack.backward(sv["arena"], pw["layers"], dx.contiguous().view(M, H), p_hid, p_att,
+        dy, layer_grads = self.stack.backward(sv["arena"], pw["layers"], dx.contiguous().view(-1, H), p_hid, p_att,
                                               sv["seed0"])
 
         # --- embeddings backward (dy = dL/dX0 [M,H]) ---
@@ -604,7 +615,8 @@ class UC2Engine(EngineBase):
 
 
 class TrunkFunction(torch.autograd.Function):
-    """autograd boundary of a native trunk: (batch, *params) -> X_final [B,S,H]."""
+    """autograd boundary of a native trunk: (batch, *params) -> X_final [B,S,H], or its pooled rows [B,1,H] when the
+    stack runs in the pooled-row mode (the heads only ever read X_final[:, 0])."""
 
     @staticmethod
     def forward(ctx, engine, training, ids, feats, locs, seg, tmask, imask, *params):

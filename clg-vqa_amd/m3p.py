@@ -206,8 +206,7 @@ class M3PEngine(EngineBase):
         sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, seed0=seed0, ids=ids, locs=locs2, pw=pw,
                   arena=ar, rowmask=rowmask, rm_img=rm_img, rm_txt=rm_txt, f_hi=f_hi, z1=z_i, mean_i=mean_i, rstd_i=rstd_i,
                   z2=a32, mean_2=mean_2, rstd_2=rstd_2, z_t=z_t, mean_t=mean_t, rstd_t=rstd_t)
-        out = self.stack.forward(ar, pw["layers"], p_hid, p_att, seed0, row_post=rowmask)
-        return out.view(B, S, H), sv
+        return self.stack.forward(ar, pw["layers"], p_hid, p_att, seed0, row_post=rowmask), sv
 
     def backward(self, sv, dx):
         c = self.model.config
@@ -220,7 +219,7 @@ class M3PEngine(EngineBase):
         p_hid, p_att, seed, pw = sv["p_hid"], sv["p_att"], sv["seed"], sv["pw"]
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         ws = ops.ln_bwd_ws(M, H, dev)
-        dy, layer_grads = self.stack.backward(sv["arena"], pw["layers"], dx.contiguous().view(M, H), p_hid, p_att,
+        dy, layer_grads = self.stack.backward(sv["arena"], pw["layers"], dx.contiguous().view(-1, H), p_hid, p_att,
                                               sv["seed0"], row_post=sv["rowmask"])
         ge = e.layer_norm_emb.weight.detach()
         dpos = torch.zeros_like(e.position_embeddings.weight)

@@ -178,6 +178,18 @@ def colsum_finalize(partial, nblk, N, outs, accumulate=False):
                                              1 if accumulate else 0, _stream()), "vl_colsum_finalize")
 
 
+def colreduce_multi(sets, accumulate=False):
+    """sets = [(src [nrows, ncols] fp32, seg, (out0, out1, out2) with None = skip), ...] (<= 4): one launch."""
+    import ctypes
+    n = len(sets)
+    arr = (ctypes.c_int64 * (8 * n))()
+    for i, (src, seg, outs) in enumerate(sets):
+        o = [0 if t is None else _p(t) for t in outs] + [0] * (3 - len(outs))
+        arr[8 * i:8 * i + 8] = [_p(src), src.shape[0], src.shape[1], seg] + o + [0]
+    _lib.check(_lib.lib().vl_colreduce_multi(ctypes.cast(arr, ctypes.c_void_p), n, 1 if accumulate else 0, _stream()),
+               "vl_colreduce_multi")
+
+
 def dw_grouped(problems, K, accumulate=False):
     """problems = [(aT_ptr_tensor, a_row0, a_rows_total, bT_tensor, b_rows_total, out [M,N] fp32, mask or None, M, N)]:
     aT / bT are blocked images (transpose_blocked); a_row0 selects a row sub-range of the A image."""
@@ -213,13 +225,14 @@ def attn2_bwd(qkv_hi, addmask, dctx16, lse, dqkv16, B, S, nh, dh, p_drop, seed, 
 
 
 def ln_fwd(y, resid, addvec, gamma, beta, eps, out32, out_hi, out_lo, mean, rstd, M, H, group=None, out_stride=0,
-           out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None):
+           out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None, orig_row_stride=1, resid_row_stride=1):
     group = M if group is None else group
     arows = 1 if addvec is None or addvec.dim() == 1 else addvec.shape[0]
     _lib.check(_lib.lib().vl_ln_fwd(_p(y), _p(resid), _p(addvec), arows, _p(row_pre), _p(row_post), _p(gamma),
                                     _p(beta), float(eps), _p(out32),
                                     _p(out_hi), _p(out_lo), _p(mean), _p(rstd), M, H, group, out_stride, out_off,
-                                    float(p_pre), float(p_post), int(seed), _stream()), "vl_ln_fwd")
+                                    float(p_pre), float(p_post), int(seed), orig_row_stride, resid_row_stride, _stream()),
+               "vl_ln_fwd")
 
 
 def ln_bwd_ws(M, H, device):
@@ -227,12 +240,12 @@ def ln_bwd_ws(M, H, device):
 
 
 def ln_bwd(dy, z, mean, rstd, gamma, dz, dpre16, dpre32, dgamma, dbeta, dbias, ws, M, H, group=None, out_stride=0,
-           out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None):
+           out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None, orig_row_stride=1):
     group = M if group is None else group
     _lib.check(_lib.lib().vl_ln_bwd(_p(dy), _p(z), _p(mean), _p(rstd), _p(gamma), _p(row_pre), _p(row_post), _p(dz),
                                     _p(dpre16), _p(dpre32),
                                     _p(dgamma), _p(dbeta), _p(dbias), _p(ws), M, H, group, out_stride, out_off,
-                                    float(p_pre), float(p_post), int(seed), _stream()), "vl_ln_bwd")
+                                    float(p_pre), float(p_post), int(seed), orig_row_stride, _stream()), "vl_ln_bwd")
 
 
 def ln_bwd_reduce(ws, M, H, dgamma, dbeta, dbias):

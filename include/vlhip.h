@@ -105,6 +105,12 @@ int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, void* stream)
 int vl_colsum_finalize(const float* partial, int64_t nblk, int64_t N, float* const* outs, int64_t nout, int accumulate,
                        void* stream);
 int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream);
+/* Up to 4 column reductions in one launch: `tab` = HOST array of n x VL_CR_FIELDS int64 {src [nrows, ncols] fp32, nrows,
+ * ncols, seg, out0, out1, out2, 0}: out_t[c] (+)= sum_rows src[row][t*seg + c] for the ncols / seg <= 3 segments (a
+ * zero out_t skips a segment).  Deterministic.  Used per layer for the LayerNorm partials of vl_ln_bwd (dgamma, dbeta,
+ * dbias) and the bias-gradient partials of vl_transpose_blocked. */
+#define VL_CR_FIELDS 8
+int vl_colreduce_multi(const int64_t* tab, int64_t n, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused V&L attention core over the single stream X = [text ; boxes]  (S = T + V <= 160, head dim 64).
@@ -157,8 +163,13 @@ int vl_attn2_bwd(const void* qkv_hi, const float* addmask, const void* dctx16, c
 int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, int64_t addvec_rows, const float* row_pre,
               const float* row_post, const float* gamma, const float* beta, float eps, float* out32, void* out_hi, void* out_lo, float* mean, float* rstd, int64_t M, int64_t H,
               int64_t group, int64_t out_stride, int64_t out_off, float p_pre, float p_post, uint64_t seed,
-              void* stream);
-/* Backward: dy32 is read through the same row map; dz32 [M,H] = dL/dz (what flows to the residual branch);
+              int64_t orig_row_stride, int64_t resid_row_stride, void* stream);
+/* Compact-row calls (orig_row_stride > 1): only a subset of the rows of a larger [M_full, H] problem is live -- the pooled
+ * row of every sample in the last layer (encoders.py:597-608 reads hidden_states[:, 0] only).  Row r of this call is row
+ * r * orig_row_stride of the full problem: the dropout counter and row_pre / row_post are indexed by that ORIGINAL row, so
+ * the result is bit-identical to the corresponding rows of the dense call; resid32 is read at row r * resid_row_stride.
+ * Pass 1, 1 for ordinary calls.
+ * Backward: dy32 is read through the same row map; dz32 [M,H] = dL/dz (what flows to the residual branch);
  * dpre16 (bf16, may be NULL) / dpre32 (fp32, may be NULL) = dL/dy = dz * keep_pre  (what flows into the producing
  * GEMM); column sums over the M rows: dgamma, dbeta, dbias (= colsum(dL/dy), the producing dense layer's bias
  * gradient; may be NULL).  partial_ws: >= vl_ln_bwd_ws_floats(M, H) floats of scratch. */
@@ -167,7 +178,7 @@ int vl_ln_debug_blocks(int n); /* A/B knob: workgroups (= partial row-sets) of v
 int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd, const float* gamma,
               const float* row_pre, const float* row_post, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta, float* dbias,
               float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
-              float p_pre, float p_post, uint64_t seed, void* stream);
+              float p_pre, float p_post, uint64_t seed, int64_t orig_row_stride, void* stream);
 /* dgamma = dbeta = dbias = NULL makes vl_ln_bwd stop after the per-workgroup partials; this sums them later, on any
  * stream ordered after that call (the engine uses the weight-gradient stream: off the backward critical path). */
 int vl_ln_bwd_reduce(const float* partial_ws, int64_t M, int64_t H, float* dgamma, float* dbeta, float* dbias,
@@ -225,6 +236,8 @@ enum {
   VL_ST_CS_QKV = 23,
   VL_ST_CS_U = 24,
   VL_ST_PROF = 25, /* HOST pointer to a VlProf block (0 = no timing), see below */
+  VL_ST_POOLED_ONLY = 26, /* != 0: only row 0 of every sample of the LAST layer's output is live (see below) */
+  VL_ST_ROWS0 = 27, /* int64 [B] device array {0, S, 2S, ...}: the live rows (pooled-row mode) */
   VL_ST_FIELDS = 32
 };
 enum {
@@ -287,7 +300,13 @@ enum {
   VL_LY_MASK0 = 71, /* 6 values */
   VL_LY_FIELDS = 80
 };
-/* Optional launch timing (benchmarks: roofline numbers measured live, on the stream the kernel runs on).  VL_ST_PROF
+/* Pooled-row mode (VL_ST_POOLED_ONLY): the head reads hidden_states[:, 0] only (BertTextPooler, encoders.py:597-608; M3P
+ * BertPooler, m3p_transformer.py:548-560), so in the last layer every row but one per sample is dead after the K/V
+ * projection.  The last layer then runs attention for query 0 only and everything after it on the B live rows in COMPACT
+ * [B, .] buffers (the first B rows of the layer's buffers): OUT32 is [B, H], and in backward DY is the [B, H] gradient of
+ * those rows.  Dropout counters and row masks are those of the original rows, so the live rows are bit-identical to the
+ * dense run; DX is the full [B*S, H] gradient.
+ * Optional launch timing (benchmarks: roofline numbers measured live, on the stream the kernel runs on).  VL_ST_PROF
  * points to a HOST int64 block owned by the caller: [0] stride (every stride-th GEMM launch is bracketed), [1] capacity
  * (event pairs), [2] launch counter, [3] pairs used, then per pair 4 values {event0, event1 (hipEvent_t handles created
  * by the caller with timing enabled), tag, flops}: the library records the events around the launch and fills tag

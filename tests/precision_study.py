@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Regenerates the precision table of DESIGN.md §2 on the CPU oracle (tools only: imports oracle/, never the product).
+"""Regenerates the precision table of DESIGN.md §2 on the CPU oracle.  (A script, not a test: it lives under tests/
+because it imports oracle/, which only tests/, smoke() and bench.py's cpu_baseline leg may do.)
 
 Every nn.Linear of the oracle (trunk + head: the 48 + 4 GEMMs of a forward) -- and, with --attn, the two attention
 products -- is replaced by a product whose OPERANDS are rounded the way a candidate MFMA scheme would feed them, with
@@ -18,7 +19,7 @@ per-tensor relative L2 error of the gradients (median / max over the 215 tensors
 fp32-grade = bf16x3, the engine's choice).  `--trajectory N` additionally trains N optimizer steps with each backward
 scheme against the fp32 run (dropout 0) and prints the loss drift: the CPU rehearsal of tests/test_gpu_trajectory.py.
 
-    python tools/precision_study.py --layers 12 --batch 8            # the table of DESIGN.md §2 (a few minutes on 8 cores)
+    python tests/precision_study.py --layers 12 --batch 8            # the table of DESIGN.md §2 (a few minutes on 8 cores)
 """
 import argparse
 import os
@@ -29,7 +30,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from helpers import TASK_CFG, uc2_cfg_dict  # noqa: E402
 from oracle import adamw_oracle as A  # noqa: E402

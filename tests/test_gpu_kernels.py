@@ -733,3 +733,19 @@ def test_dw_grouped_matches_fp64(K):
     o2 = torch.full((320, 192), float("nan"), device=DEV)
     ops.dw_grouped([(oimg[0], 0, 320, oimg[1], 192, o2, None, 320, 192)], K)
     torch.testing.assert_close(o2.double(), odd_a.double().t() @ odd_b.double(), rtol=2e-5, atol=tol)
+
+
+def test_colreduce_multi_matches_fp64_and_accumulates():
+    a = _rand(513, 2304, seed=90)
+    b = _rand(224, 3072, seed=91)
+    c = _rand(7, 64, seed=92)
+    oa = [torch.full((768,), float("nan"), device=DEV) for _ in range(3)]
+    ob = [torch.full((3072,), float("nan"), device=DEV)]
+    oc = [torch.full((32,), float("nan"), device=DEV), None]
+    ops.colreduce_multi([(a, 768, oa), (b, 3072, ob), (c, 32, oc)])
+    torch.testing.assert_close(torch.cat(oa).double(), a.double().sum(0), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(ob[0].double(), b.double().sum(0), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(oc[0].double(), c.double().sum(0)[:32], rtol=1e-5, atol=1e-5)
+    first = torch.cat(oa).clone()
+    ops.colreduce_multi([(a, 768, oa)], accumulate=True)
+    assert torch.equal(torch.cat(oa), first + first)

@@ -213,6 +213,42 @@ def test_c5_sft_masks_with_100_boxes_together():
         assert (gr - r).norm().item() <= GRAD_REL_L2 * r.norm().item(), n
 
 
+@pytest.mark.parametrize("B,T,V,train", [(8, 20, 36, True), (3, 7, 9, True), (5, 40, 100, False)])
+def test_pooled_row_mode_equals_the_dense_run(B, T, V, train):
+    """The last layer only computes the pooled row of every sample (the head reads hidden_states[:, 0],
+    encoders.py:597-608).  Against the dense run -- same weights, batch, dropout seeds (dropout ON) -- the logits are
+    bit-equal and every gradient agrees to fp32 rounding (the weight gradients of the last layer sum the same non-zero
+    addends in a different grouping: the dense run also adds the exact zeros of the dead rows)."""
+    config = BertConfig.from_dict(uc2_cfg_dict(n_layers=3, vocab=800))
+    model, _ = _build(config, seed=29)
+    batch = make_batch(B, seq_len=T, num_boxes=V, vocab_size=800, seed=300 + B)
+    batch[2][0, V - 2:] = 0
+    res = {}
+    for mode in (False, True):
+        model.engine.stack.pooled_only = mode
+        model.engine.calls = 0
+        torch.manual_seed(5)  # the head's torch dropout
+        loss, _, _ = _run_native(model, batch, train_mode=train)
+        model.engine.calls = 100
+        with torch.no_grad():
+            model.eval()
+            b = tuple(t.cuda() for t in batch)
+            logits = model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])[0].clone()
+        res[mode] = (float(loss), logits, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    assert res[False][0] == res[True][0]
+    assert torch.equal(res[False][1], res[True][1])
+    worst = (0.0, None)
+    for n, g in res[False][2].items():
+        g2 = res[True][2][n]
+        rel = (g.double() - g2.double()).norm().item() / max(g.double().norm().item(), 1e-30)
+        worst = max(worst, (rel, n))
+        if n.endswith("attention_self.key.bias"):
+            continue
+        assert rel <= 2e-6, (n, rel)
+    print("pooled vs dense (B=%d S=%d train=%s): loss equal, logits bit-equal, worst gradient rel diff %.2e at %s" % (
+        B, T + V, train, worst[0], worst[1]))
+
+
 def test_training_mode_dropout_runs_and_is_seeded():
     config = BertConfig.from_dict(uc2_cfg_dict(n_layers=2, vocab=500))
     model, _ = _build(config, seed=5)

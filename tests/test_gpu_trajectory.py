@@ -21,7 +21,7 @@ from clg_vqa_amd.synthetic import make_batch, seeded_state_dict  # noqa: E402
 
 # Stated tolerances.  The loss is CE * 1842 (~1.3e4): 1e-3 relative is ~0.1 % of it.  Measured drift is printed.
 LOSS_REL_TOL = 1e-3
-PARAM_DEV_TOL = 0.5       # ||theta_native - theta_oracle|| / ||theta_oracle - theta_0|| per tensor after N steps (Adam's
+PARAM_DEV_TOL = 0.05      # ||theta_native - theta_oracle|| / ||theta_oracle - theta_0|| per tensor after N steps (Adam's
                           # sign-like first updates turn gradient noise on near-zero entries into +-lr steps: reported)
 
 

@@ -56,7 +56,11 @@ def main():
         traffic[k] = dict(launches=n, hbm_read_MB_per_launch=fetch / 1e6, hbm_write_MB_per_launch=write / 1e6,
                           l2_hit_rate=hit / max(hit + miss, 1.0),
                           lds_bank_conflict_frac=c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
-                          wait_any_frac=c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 0.0), 1.0))
+                          wait_any_frac=c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 0.0), 1.0),
+                          # rocprofv3's MfmaUtil: sum(SQ_VALU_MFMA_BUSY_CYCLES) / (GRBM_GUI_ACTIVE of one XCD * 1024 SIMDs);
+                          # GRBM_GUI_ACTIVE is reported summed over the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back)
+                          mfma_busy_frac=(c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c.get("GRBM_GUI_ACTIVE", 0.0) / 8 * 1024, 1.0)
+                                          if "SQ_VALU_MFMA_BUSY_CYCLES" in c else None))
     out = dict(round=args.round, gpu_ms_per_step=total / 1e6 / args.steps, kernels=kernels, pmc=traffic)
     with open(os.path.join(args.out, "%s_summary.json" % args.round), "w") as fo:
         json.dump(out, fo, indent=1)
