@@ -29,7 +29,7 @@ _SIGS = {
     "vl_ln_bwd_reduce": (c_int, [P, c_int64, c_int64, P, P, P, P]),
     "vl_ln_bwd_reduce2": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, c_int64, c_int, P]),
     "vl_stack_desc_len": (c_int64, [c_int64]),
-    "vl_stack_fwd": (c_int, [P, c_int64, c_int64, P]),
+    "vl_stack_fwd": (c_int, [P, c_int64, c_int64, P, P]),
     "vl_stack_bwd": (c_int, [P, c_int64, c_int64, P, P]),
     "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),

@@ -65,7 +65,7 @@ int check_header(const char* fn, const int64_t* d) {
 
 extern "C" int64_t vl_stack_desc_len(int64_t n_layers) { return VL_ST_FIELDS + n_layers * VL_LY_FIELDS; }
 
-extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer_end, void* stream) {
+extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer_end, void* stream, void* stream_side) {
   VL_TRY(check_header("vl_stack_fwd", d));
   const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I], nh = d[VL_ST_NH], L = d[VL_ST_NLAYERS];
   VL_CHECK_ARG(layer_begin >= 0 && layer_begin <= layer_end && layer_end <= L, "vl_stack_fwd: bad layer range");
@@ -74,6 +74,8 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
   const float* addmask = ptr<const float>(d[VL_ST_ADDMASK]);
   const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
   int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
+  hipStream_t ss = stream_side ? (hipStream_t)stream_side : (hipStream_t)stream;
+  hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);
   for (int64_t l = layer_begin; l < layer_end; ++l) {
     const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
     const int s3 = (int)(16 * l + 3);
@@ -105,6 +107,27 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
                      ptr<const float>(y[VL_LY_LN2_G]), ptr<const float>(y[VL_LY_LN2_B]), eps, ptr<float>(y[VL_LY_OUT32]),
                      ptr<void>(y[VL_LY_OUT_HI]), ptr<void>(y[VL_LY_OUT_LO]), ptr<float>(y[VL_LY_MEAN2]), ptr<float>(y[VL_LY_RSTD2]),
                      R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 2), os, 1, stream));
+    if (y[VL_LY_T_X]) {
+      // training: the K-major images of this layer's X operands for the weight-gradient GEMMs of backward, written now,
+      // behind the layer, on the side stream -- the forward is MFMA-bound, its HBM bandwidth is idle
+      if (ss != (hipStream_t)stream) {
+        VL_CHECK_ARG(fork, "vl_stack_fwd: a side stream needs the fork event of the descriptor");
+        hipError_t e = hipEventRecord(fork, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ss, fork, 0);
+        if (e != hipSuccess) return vl_set_error(-3, "vl_stack_fwd: stream fork: %s", hipGetErrorString(e));
+      }
+      const int64_t tr[4 * VL_TR_FIELDS] = {
+          y[VL_LY_X_HI], H, H, y[VL_LY_T_X], 0, 0,
+          y[VL_LY_CTX_HI], H, H, y[VL_LY_T_CTX], 0, 0,
+          y[VL_LY_X1_HI], H, H, y[VL_LY_T_X1], 0, 0,
+          y[VL_LY_H_HI], I, I, y[VL_LY_T_H], 0, 0};
+      if (pooled) {
+        VL_TRY(vl_transpose_blocked(tr, 1, M, ss));
+        VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, ss));
+      } else {
+        VL_TRY(vl_transpose_blocked(tr, 4, M, ss));
+      }
+    }
   }
   return 0;
 }
@@ -163,20 +186,18 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
                                   -1, nullptr, sm));
     // ---- optimizer-only work: K-major re-layout, column sums, grouped weight-gradient GEMM ---------------------------
     const int64_t mblk = (M + 63) / 64, rblk = (R + 63) / 64;
-    const int64_t tr[8 * VL_TR_FIELDS] = {
+    const int64_t tr[4 * VL_TR_FIELDS] = {
         y[VL_LY_DQKV], 3 * H, 3 * H, d[VL_ST_T_DQKV], d[VL_ST_CS_QKV], 0,
-        y[VL_LY_X_HI], H, H, d[VL_ST_T_X], 0, 0,
         y[VL_LY_DT1], H, H, d[VL_ST_T_DT1], 0, 0,
         y[VL_LY_DU16], I, I, d[VL_ST_T_DU], d[VL_ST_CS_U], 0,
-        y[VL_LY_DT2], H, H, d[VL_ST_T_DT2], 0, 0,
-        y[VL_LY_CTX_HI], H, H, d[VL_ST_T_CTX], 0, 0,
-        y[VL_LY_X1_HI], H, H, d[VL_ST_T_X1], 0, 0,
-        y[VL_LY_H_HI], I, I, d[VL_ST_T_H], 0, 0};
-    if (pooled) {  // the first two operands have M rows, the other six only the B live ones
-      VL_TRY(vl_transpose_blocked(tr, 2, M, ss));
-      VL_TRY(vl_transpose_blocked(tr + 2 * VL_TR_FIELDS, 6, R, ss));
+        y[VL_LY_DT2], H, H, d[VL_ST_T_DT2], 0, 0};
+    VL_CHECK_ARG(y[VL_LY_T_X] && y[VL_LY_T_CTX] && y[VL_LY_T_X1] && y[VL_LY_T_H],
+                 "vl_stack_bwd: the layer record lacks the K-major X images (forward ran without them)");
+    if (pooled) {  // dqkv has M rows, the other three only the B live ones
+      VL_TRY(vl_transpose_blocked(tr, 1, M, ss));
+      VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, ss));
     } else {
-      VL_TRY(vl_transpose_blocked(tr, 8, M, ss));
+      VL_TRY(vl_transpose_blocked(tr, 4, M, ss));
     }
     // one launch: LayerNorm partials -> (dgamma, dbeta, bias gradient of the producing Linear) x 2, column-sum partials
     // of dqkv -> (bq, bk, bv) and of du -> b1
@@ -188,12 +209,12 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
         d[VL_ST_CS_U], rblk, I, I, y[VL_LY_GRAD0 + 11], 0, 0, 0};
     VL_TRY(vl_colreduce_multi(cr, 4, accumulate, ss));
     const int64_t pr[6 * VL_DW_FIELDS] = {
-        d[VL_ST_T_DQKV], 3 * H, d[VL_ST_T_X], H, y[VL_LY_GRAD0 + 0], H, y[VL_LY_MASK0 + 0], H, H, 0,
-        d[VL_ST_T_DQKV] + 2 * 64 * H, 3 * H, d[VL_ST_T_X], H, y[VL_LY_GRAD0 + 2], H, y[VL_LY_MASK0 + 1], H, H, 0,
-        d[VL_ST_T_DQKV] + 2 * 64 * 2 * H, 3 * H, d[VL_ST_T_X], H, y[VL_LY_GRAD0 + 4], H, y[VL_LY_MASK0 + 2], H, H, 0,
-        d[VL_ST_T_DT1], H, d[VL_ST_T_CTX], H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
-        d[VL_ST_T_DU], I, d[VL_ST_T_X1], H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, 0,
-        d[VL_ST_T_DT2], H, d[VL_ST_T_H], I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
+        d[VL_ST_T_DQKV], 3 * H, y[VL_LY_T_X], H, y[VL_LY_GRAD0 + 0], H, y[VL_LY_MASK0 + 0], H, H, 0,
+        d[VL_ST_T_DQKV] + 2 * 64 * H, 3 * H, y[VL_LY_T_X], H, y[VL_LY_GRAD0 + 2], H, y[VL_LY_MASK0 + 1], H, H, 0,
+        d[VL_ST_T_DQKV] + 2 * 64 * 2 * H, 3 * H, y[VL_LY_T_X], H, y[VL_LY_GRAD0 + 4], H, y[VL_LY_MASK0 + 2], H, H, 0,
+        d[VL_ST_T_DT1], H, y[VL_LY_T_CTX], H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
+        d[VL_ST_T_DU], I, y[VL_LY_T_X1], H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, 0,
+        d[VL_ST_T_DT2], H, y[VL_LY_T_H], I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
     if (pooled) {  // Q/K/V gradients reduce over all M rows, the other three over the B live rows
       VL_TRY(vl_dw_grouped(pr, 3, M, accumulate, ss));
       VL_TRY(vl_dw_grouped(pr + 3 * VL_DW_FIELDS, 3, R, accumulate, ss));

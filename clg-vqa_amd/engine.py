@@ -205,7 +205,9 @@ class StackArena(object):
             self.lnws1, self.lnws2 = f32(L, nws), f32(L, nws)
             img = lambda N: b16(lib.vl_blocked_elems(M, N))  # noqa: E731
             self.t_dqkv, self.t_dt1, self.t_du, self.t_dt2 = img(3 * H), img(H), img(I), img(H)
-            self.t_x, self.t_ctx, self.t_x1, self.t_h = img(H), img(H), img(H), img(I)
+            # K-major images of the X operands: per layer, written during forward on the side stream
+            nx, ni = lib.vl_blocked_elems(M, H), lib.vl_blocked_elems(M, I)
+            self.t_x, self.t_ctx, self.t_x1, self.t_h = b16(L, nx), b16(L, nx), b16(L, nx), b16(L, ni)
             mb = (M + 63) // 64
             self.cs_qkv, self.cs_u = f32(mb, 3 * H), f32(mb, I)
             self.fork = torch.cuda.Event()
@@ -280,7 +282,7 @@ class LayerStack(object):
         d[VL["VL_ST_ROWS0"]] = ar.rows0.data_ptr()
         if ar.need_grad:
             d[VL["VL_ST_EV_FORK"]] = ar.fork.cuda_event
-            for k in ("t_dqkv", "t_dt1", "t_du", "t_dt2", "t_x", "t_ctx", "t_x1", "t_h", "cs_qkv", "cs_u"):
+            for k in ("t_dqkv", "t_dt1", "t_du", "t_dt2", "cs_qkv", "cs_u"):
                 d[VL["VL_ST_" + k.upper()]] = getattr(ar, k).data_ptr()
         it = iter(ptrs)
         for l in range(L):
@@ -308,7 +310,7 @@ class LayerStack(object):
                 put("DX", ar.dbuf[l % 2])
                 put("DY", ar.dbuf[(l + 1) % 2])  # (the top layer's DY is patched per backward)
                 put("DZ2", ar.dz2); put("DX1", ar.dx1); put("DZ1", ar.dz1); put("DCTX16", ar.dctx16)
-                for name in ("dt2", "du16", "dt1", "dqkv", "lnws1", "lnws2"):
+                for name in ("dt2", "du16", "dt1", "dqkv", "lnws1", "lnws2", "t_x", "t_ctx", "t_x1", "t_h"):
                     put(name.upper(), getattr(ar, name)[l])
         self._desc[id(ar)] = (fp, d)
         return d
@@ -325,7 +327,15 @@ class LayerStack(object):
         d[VL["VL_ST_ROW_POST"]] = 0 if row_post is None else ar.row_post.data_ptr()
         d[VL["VL_ST_PROF"]] = 0 if self.prof is None else self.prof.ctypes.data
         d[VL["VL_ST_POOLED_ONLY"]] = 1 if self.pooled_only else 0
-        ops.stack_fwd(d, 0, len(self.specs))
+        side_ptr = None
+        if ar.need_grad and self.overlap_dw:
+            dev = ar.x32.device
+            if self._side is None or self._side.device != dev:
+                self._side = torch.cuda.Stream(device=dev)
+            # (a forward whose backward never ran may still have its re-layout in flight on the side stream)
+            torch.cuda.current_stream().wait_stream(self._side)
+            side_ptr = self._side.cuda_stream
+        ops.stack_fwd(d, 0, len(self.specs), side_ptr)
         L = len(self.specs)
         if ar.need_grad:
             ar.in_flight = True

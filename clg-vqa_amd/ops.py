@@ -151,9 +151,9 @@ def gemm_tn_grouped(problems, K, splits=0):
                "vl_gemm_tn_grouped")
 
 
-def stack_fwd(desc, layer_begin, layer_end):
+def stack_fwd(desc, layer_begin, layer_end, stream_side=None):
     """desc: numpy int64 descriptor (engine.LayerStack._descriptor)."""
-    _lib.check(_lib.lib().vl_stack_fwd(desc.ctypes.data, layer_begin, layer_end, _stream()), "vl_stack_fwd")
+    _lib.check(_lib.lib().vl_stack_fwd(desc.ctypes.data, layer_begin, layer_end, _stream(), stream_side), "vl_stack_fwd")
 
 
 def stack_bwd(desc, layer_hi, layer_lo, stream_main, stream_side):

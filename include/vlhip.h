@@ -196,7 +196,8 @@ int vl_ln_bwd_reduce2(const float* ws_a, int64_t M_a, float* dgamma_a, float* db
  * Header: dims; eps / p_hid / p_att as float BITS; seed0 (site s of layer l draws from seed0*4096 + 16 l + s); addmask
  * [B*S]; row_post [B*S] or 0 (M3P `tensor *= mask`); EV_FORK = a hipEvent_t of the caller (stream fork, backward);
  * ACCUMULATE != 0 adds the gradients to their destinations; T_* = blocked K-major images (vl_blocked_elems(B*S, N)
- * bf16 each) and CS_* = column-sum partials ([ceil(B*S/64), N] fp32), scratch of the weight-gradient stream.
+ * bf16 each; the X-side fields T_X / T_CTX / T_X1 / T_H of the HEADER are unused since the images became per-layer)
+ * and CS_* = column-sum partials ([ceil(B*S/64), N] fp32), scratch of the weight-gradient stream.
  * Layer: X32 / X_HI / X_LO = the layer's input (fp32 stream + its split), OUT* = its output (= the next layer's input);
  * prepared weights W*_HI / W*_LO [N,K], W*_T = transposed hi [K,N], biases, LayerNorm parameters; the activations saved
  * for backward (QKV_HI/LO [B*S,3H], CTX_HI/LO, LSE, Z1, MEAN1, RSTD1, X1_*, U16, H_HI/LO, Z2, MEAN2, RSTD2); backward
@@ -204,7 +205,10 @@ int vl_ln_bwd_reduce2(const float* ws_a, int64_t M_a, float* dgamma_a, float* db
  * vl_ln_bwd_ws_floats(B*S, H) floats each -- DT2 / DU16 / DT1 / DQKV / LNWS* are read by the side stream and must be
  * private to the layer); GRAD0..GRAD0+15 = gradient destinations in the order {Wq, bq, Wk, bk, Wv, bv, Wo, bo, ln1.g,
  * ln1.b, W1, b1, W2, b2, ln2.g, ln2.b}; MASK0..MASK0+5 = SFT masks of {Wq, Wk, Wv, Wo, W1, W2} (fp32, 0 = dense).
- * vl_stack_fwd runs layers [layer_begin, layer_end) on `stream`; vl_stack_bwd runs layers [layer_lo, layer_hi) in
+ * vl_stack_fwd runs layers [layer_begin, layer_end) on stream_main; when the layer records carry T_X / T_CTX / T_X1 /
+ * T_H (training), the K-major images of the layer's X operands {layer input, attention context, LayerNorm-1 output,
+ * GELU output} are written behind each layer on stream_side (HBM-bound work under the MFMA-bound forward GEMMs), so
+ * that backward only re-lays the four dY operands.  vl_stack_bwd runs layers [layer_lo, layer_hi) in
  * descending order: the critical path on stream_main, the optimizer-only work (K-major re-layout, column sums, grouped
  * weight-gradient GEMM) forked per layer onto stream_side (NULL = everything on stream_main); the caller joins them.
  * ------------------------------------------------------------------------------------------------------------ */
@@ -298,7 +302,11 @@ enum {
   VL_LY_LNWS2 = 54,
   VL_LY_GRAD0 = 55, /* 16 values */
   VL_LY_MASK0 = 71, /* 6 values */
-  VL_LY_FIELDS = 80
+  VL_LY_T_X = 77, /* per-layer K-major images of the X operands, written during FORWARD (0 = inference) */
+  VL_LY_T_CTX = 78,
+  VL_LY_T_X1 = 79,
+  VL_LY_T_H = 80,
+  VL_LY_FIELDS = 96
 };
 /* Pooled-row mode (VL_ST_POOLED_ONLY): the head reads hidden_states[:, 0] only (BertTextPooler, encoders.py:597-608; M3P
  * BertPooler, m3p_transformer.py:548-560), so in the last layer every row but one per sample is dead after the K/V
@@ -314,7 +322,7 @@ enum {
 #define VL_PROF_HEADER 4
 #define VL_PROF_PAIR 4
 int64_t vl_stack_desc_len(int64_t n_layers);
-int vl_stack_fwd(const int64_t* desc, int64_t layer_begin, int64_t layer_end, void* stream);
+int vl_stack_fwd(const int64_t* desc, int64_t layer_begin, int64_t layer_end, void* stream_main, void* stream_side);
 int vl_stack_bwd(const int64_t* desc, int64_t layer_hi, int64_t layer_lo, void* stream_main, void* stream_side);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -43,8 +43,8 @@ def main():
     for g in sorted(gaps, reverse=True)[:8]:
         print("    %.1f us before %s" % (g[0] / 1e3, g[1]))
     # forward / backward split: first attn_bwd marks the backward
-    fb = next(r for r in step if r[2].startswith("attn_bwd"))
-    lf = [r for r in step if r[0] < fb[0] and r[2].startswith("attn_fwd")][-1]
+    fb = next(r for r in step if r[2].startswith("attn2_bwd") or r[2].startswith("attn_bwd"))
+    lf = [r for r in step if r[0] < fb[0] and (r[2].startswith("attn2_fwd") or r[2].startswith("attn_fwd"))][-1]
     print("forward+head span ~%.3f ms (to last attn_fwd end), backward+opt span ~%.3f ms" % ((lf[1] - t0) / 1e6, (t1 - lf[1]) / 1e6))
 
 
