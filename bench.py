@@ -239,6 +239,8 @@ def main():
             w.data.mul_(mask)
             prune.CustomFromMask.apply(mods[n], "weight", mask=mask)
             masked_elems += w.numel()
+    if os.environ.get("BENCH_TR_BLOCKS"):  # A/B: workgroup caps of the K-major re-layout launches, "fwd,bwd"
+        model.engine.stack.tr_blocks = tuple(int(x) for x in os.environ["BENCH_TR_BLOCKS"].split(","))
     if os.environ.get("BENCH_NO_OVERLAP", "0") == "1":  # A/B: weight-gradient work on the main stream
         model.engine.stack.overlap_dw = False
     model.train()

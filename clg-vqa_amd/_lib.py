@@ -34,7 +34,7 @@ _SIGS = {
     "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_blocked_elems": (c_int64, [c_int64, c_int64]),
-    "vl_transpose_blocked": (c_int, [P, c_int64, c_int64, P]),
+    "vl_transpose_blocked": (c_int, [P, c_int64, c_int64, c_int64, P]),
     "vl_colsum_finalize": (c_int, [P, c_int64, c_int64, P, c_int64, c_int, P]),
     "vl_dw_grouped": (c_int, [P, c_int64, c_int64, c_int, P]),
     "vl_colreduce_multi": (c_int, [P, c_int64, c_int, P]),
@@ -46,6 +46,8 @@ _SIGS = {
     "vl_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64,
                           c_float, c_float, c_uint64, c_int64, P]),
     "vl_memset_zero": (c_int, [P, c_int64, P]),
+    "vl_gqa_loss_ws_bytes": (c_int64, [c_int64]),
+    "vl_gqa_loss": (c_int, [P, P, P, c_int64, c_int64, c_float, P, P, P, P]),
     "vl_mask_mul": (c_int, [P, P, P, c_int64, P]),
     "vl_weight_prep": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "vl_imp_ws_bytes": (c_int64, [c_int64]),
@@ -63,7 +65,7 @@ _SIGS = {
     "vl_loc_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_loc_linear_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_adamw": (c_int, [P, P, P, P, c_int64, P, P, P, c_int64, c_float, c_float, c_float, c_int64, c_int, c_float,
-                         P, c_float, c_int, P, c_int64, c_int64, c_int64, P]),
+                         P, c_float, P, c_float, c_float, P, c_int, P, c_int64, c_int64, c_int64, P]),
     "vl_sumsq": (c_int, [P, c_int64, P, P]),
     "vl_sumsq_flagged": (c_int, [P, c_int64, P, P, c_int64, c_int64, c_int64, P]),
 }

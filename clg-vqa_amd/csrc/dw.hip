@@ -354,7 +354,7 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) 
 extern "C" int64_t vl_blocked_elems(int64_t M, int64_t N) { return ((M + 63) / 64) * 64 * N; }
 
 // tab: HOST array of n x VL_TR_FIELDS int64 {src, ld, N, dst, colsum_partial (0 = none), 0}
-extern "C" int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, void* stream) {
+extern "C" int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, int64_t max_blocks, void* stream) {
   VL_CHECK_ARG(tab && n >= 1 && n <= MAXT && M >= 1 && M < (1LL << 31), "vl_transpose_blocked: bad arguments");
   TrArgs a{};
   a.n = (int)n; a.M = (int)M; a.mblocks = (int)((M + 63) / 64);
@@ -369,7 +369,9 @@ extern "C" int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, vo
     units += a.mblocks * (e.N >> 6);
   }
   a.total_units = units;
-  int grid = units < 4096 ? units : 4096;
+  // fewer workgroups = a gentler stream beside MFMA-bound kernels (each holds 8 KB in flight): the caller picks
+  const int cap = max_blocks > 0 ? (int)(max_blocks < 65536 ? max_blocks : 65536) : 4096;
+  int grid = units < cap ? units : cap;
   hipLaunchKernelGGL(transpose_blocked_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   VL_CHECK_LAUNCH("vl_transpose_blocked");
   return 0;

@@ -333,7 +333,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     const float* __restrict__ seg_lr,
                                                     const float* __restrict__ seg_wd, int nseg, float b1, float b2,
                                                     float eps, float bc, float lr_mult, const float* gscale_ptr,
-                                                    float gscale_const, int zero_grad,
+                                                    float gscale_const, const float* sumsq_ptr, float max_norm, float post,
+                                                    float* sumsq_next, int zero_grad,
                                                     const unsigned char* __restrict__ row_flags, long fl_beg4, long fl_end4,
                                                     int fl_row4) {
   // segment table (every segment starts on a multiple of 4 elements) -> LDS, in float4 units
@@ -345,7 +346,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     s_wd[i] = seg_wd[i];
   }
   __syncthreads();
-  const float gs = gscale_ptr ? *gscale_ptr : gscale_const;
+  float gs = gscale_ptr ? *gscale_ptr : gscale_const;
+  if (sumsq_ptr) {
+    // clip_grad_norm_ (train_task.py:330) on the device: ||g|| of the averaged gradient = sqrt(sum g^2) * post;
+    // coefficient min(1, max_norm / (||g|| + 1e-6)), times the 1/world factor `post` of the all-reduce
+    const float norm = sqrtf(*sumsq_ptr) * post;
+    gs = fminf(max_norm / (norm + 1e-6f), 1.0f) * post;
+  }
+  if (sumsq_next && blockIdx.x == 0 && threadIdx.x == 0) *sumsq_next = 0.f;  // the NEXT step's accumulator (nobody reads it now)
   const float c1 = 1.f - b1, c2 = 1.f - b2;
   const long stride = (long)gridDim.x * blockDim.x;
   auto seg_of = [&](long i) {  // first segment whose end > i
@@ -589,7 +597,8 @@ extern "C" int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw,
 extern "C" int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1,
                         float beta2, float eps, int64_t step, int correct_bias, float lr_mult,
-                        const float* grad_scale_dev, float grad_scale, int zero_grad, const uint8_t* row_flags,
+                        const float* grad_scale_dev, float grad_scale, const float* sumsq_dev, float max_norm, float post,
+                        float* sumsq_next, int zero_grad, const uint8_t* row_flags,
                         int64_t flag_begin, int64_t flag_rows, int64_t flag_row_len, void* stream) {
   VL_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && seg_end && seg_lr && seg_wd && n > 0 && nseg > 0 && step > 0,
                "vl_adamw: bad arguments");
@@ -604,7 +613,7 @@ extern "C" int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_av
   if (correct_bias) bc = (float)(sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step)));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, param, grad,
                      exp_avg, exp_avg_sq, (long)(n / 4), seg_end, seg_lr, seg_wd, (int)nseg, beta1, beta2, eps, bc, lr_mult,
-                     grad_scale_dev, grad_scale, zero_grad, row_flags, (long)(flag_begin / 4),
+                     grad_scale_dev, grad_scale, sumsq_dev, max_norm, post, sumsq_next, zero_grad, row_flags, (long)(flag_begin / 4),
                      (long)((flag_begin + flag_rows * flag_row_len) / 4), (int)(flag_row_len / 4));
   VL_CHECK_LAUNCH("vl_adamw");
   return 0;

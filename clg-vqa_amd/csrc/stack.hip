@@ -122,10 +122,10 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
           y[VL_LY_X1_HI], H, H, y[VL_LY_T_X1], 0, 0,
           y[VL_LY_H_HI], I, I, y[VL_LY_T_H], 0, 0};
       if (pooled) {
-        VL_TRY(vl_transpose_blocked(tr, 1, M, ss));
-        VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, ss));
+        VL_TRY(vl_transpose_blocked(tr, 1, M, d[VL_ST_TR_BLOCKS_FWD], ss));
+        VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, d[VL_ST_TR_BLOCKS_FWD], ss));
       } else {
-        VL_TRY(vl_transpose_blocked(tr, 4, M, ss));
+        VL_TRY(vl_transpose_blocked(tr, 4, M, d[VL_ST_TR_BLOCKS_FWD], ss));
       }
     }
   }
@@ -194,10 +194,10 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
     VL_CHECK_ARG(y[VL_LY_T_X] && y[VL_LY_T_CTX] && y[VL_LY_T_X1] && y[VL_LY_T_H],
                  "vl_stack_bwd: the layer record lacks the K-major X images (forward ran without them)");
     if (pooled) {  // dqkv has M rows, the other three only the B live ones
-      VL_TRY(vl_transpose_blocked(tr, 1, M, ss));
-      VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, ss));
+      VL_TRY(vl_transpose_blocked(tr, 1, M, d[VL_ST_TR_BLOCKS_BWD], ss));
+      VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, d[VL_ST_TR_BLOCKS_BWD], ss));
     } else {
-      VL_TRY(vl_transpose_blocked(tr, 4, M, ss));
+      VL_TRY(vl_transpose_blocked(tr, 4, M, d[VL_ST_TR_BLOCKS_BWD], ss));
     }
     // one launch: LayerNorm partials -> (dgamma, dbeta, bias gradient of the producing Linear) x 2, column-sum partials
     // of dqkv -> (bq, bk, bv) and of du -> b1

@@ -75,16 +75,28 @@ class PreparedWeight(object):
             r += n
         return rows
 
-    def _pack_bias(self):
+    def bias_pairs(self):
+        """(destination view, source bias) pairs of a packed bias buffer (empty for a single Linear, whose bias IS the
+        parameter): the engine batches the pairs of all layers into one multi-tensor copy per step."""
         if len(self.linears) == 1:
             b = self.linears[0].bias.detach()
             if b.data_ptr() != self.bias.data_ptr():
                 self.bias = b
-        else:
-            torch.cat([l.bias.detach() for l in self.linears], out=self.bias)
+            return []
+        pairs, r = [], 0
+        for l in self.linears:
+            pairs.append((self.bias[r:r + l.out_features], l.bias.detach()))
+            r += l.out_features
+        return pairs
 
-    def refresh_bias(self, fingerprint=True):
-        self._pack_bias()
+    def _pack_bias(self):
+        pairs = self.bias_pairs()
+        if pairs:
+            torch._foreach_copy_([d for d, _ in pairs], [s for _, s in pairs])
+
+    def refresh_bias(self, fingerprint=True, pack=True):
+        if pack:
+            self._pack_bias()
         # after an explicit mark_dirty() the version fingerprint is left empty: the next call that is not preceded by
         # an optimizer step sees a mismatch, prepares once more and records the real fingerprint
         self.key = self._key() if fingerprint else None
@@ -229,6 +241,7 @@ class LayerStack(object):
         # last layer then runs on the B live rows after its K/V projection and the stack returns [B, 1, H] (exact: the
         # live rows are bit-identical to the dense run, the dead ones are never computed)
         self.pooled_only = True
+        self.tr_blocks = (0, 0)  # workgroup caps of the K-major re-layout launches (forward, backward); 0 = default
         self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
         # callable(layer) -> (16 destination views in LayerSpec.params order, accumulate) or None: when the optimizer
         # provides it, gradients are written straight into its flat arena
@@ -327,6 +340,7 @@ class LayerStack(object):
         d[VL["VL_ST_ROW_POST"]] = 0 if row_post is None else ar.row_post.data_ptr()
         d[VL["VL_ST_PROF"]] = 0 if self.prof is None else self.prof.ctypes.data
         d[VL["VL_ST_POOLED_ONLY"]] = 1 if self.pooled_only else 0
+        d[VL["VL_ST_TR_BLOCKS_FWD"]], d[VL["VL_ST_TR_BLOCKS_BWD"]] = self.tr_blocks
         side_ptr = None
         if ar.need_grad and self.overlap_dw:
             dev = ar.x32.device
@@ -471,8 +485,11 @@ class EngineBase(object):
                 pw["table"] = torch.tensor(rows, dtype=torch.int64).to(device)
                 pw["table_ident"], pw["table_tiles"] = ident, tile0
             ops.weight_prep_multi(pw["table"], pw["table"].shape[0], pw["table_tiles"])  # one launch per step
+            pairs = [pr for p in all_pw for pr in p.bias_pairs()]
+            if pairs:  # the packed [Q|K|V] biases of all layers: one multi-tensor copy
+                torch._foreach_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs])
             for p in all_pw:
-                p.refresh_bias(fingerprint=not explicit)
+                p.refresh_bias(fingerprint=not explicit, pack=False)
         self._dirty = False
         return pw
 

@@ -160,7 +160,7 @@ def stack_bwd(desc, layer_hi, layer_lo, stream_main, stream_side):
     _lib.check(_lib.lib().vl_stack_bwd(desc.ctypes.data, layer_hi, layer_lo, stream_main, stream_side), "vl_stack_bwd")
 
 
-def transpose_blocked(entries, M):
+def transpose_blocked(entries, M, max_blocks=0):
     """entries = [(src [M,N] bf16 (row-major, ld = stride(0)), dst blocked image, colsum_partial or None), ...]"""
     import ctypes
     n = len(entries)
@@ -168,7 +168,8 @@ def transpose_blocked(entries, M):
     for i, (src, dst, cs) in enumerate(entries):
         ps, ld = _pld(src)
         arr[6 * i:6 * i + 6] = [ps, ld, src.shape[1], _p(dst), 0 if cs is None else _p(cs), 0]
-    _lib.check(_lib.lib().vl_transpose_blocked(ctypes.cast(arr, ctypes.c_void_p), n, M, _stream()), "vl_transpose_blocked")
+    _lib.check(_lib.lib().vl_transpose_blocked(ctypes.cast(arr, ctypes.c_void_p), n, M, max_blocks, _stream()),
+               "vl_transpose_blocked")
 
 
 def colsum_finalize(partial, nblk, N, outs, accumulate=False):
@@ -261,6 +262,12 @@ def ln_bwd_reduce2(ws_a, M_a, outs_a, ws_b, M_b, outs_b, H, accumulate=False):
                "vl_ln_bwd_reduce2")
 
 
+def gqa_loss(logits, target, distances, semantic_lambda, loss_score, dlogits, ws):
+    B, C = logits.shape
+    _lib.check(_lib.lib().vl_gqa_loss(_p(logits), _p(target), _p(distances), B, C, float(semantic_lambda), _p(loss_score),
+                                      _p(dlogits), _p(ws), _stream()), "vl_gqa_loss")
+
+
 def memset_zero(t):
     _lib.check(_lib.lib().vl_memset_zero(_p(t), t.numel() * t.element_size(), _stream()), "vl_memset_zero")
 
@@ -346,11 +353,13 @@ def loc_linear_bwd(loc, dy32, dw, db, R, L, H):
 
 def adamw(param, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, seg_wd, beta1, beta2, eps, step, correct_bias, lr_mult,
           grad_scale_dev=None, grad_scale=1.0, zero_grad=False, row_flags=None, flag_begin=0, flag_rows=0,
-          flag_row_len=0):
+          flag_row_len=0, sumsq=None, max_norm=0.0, post=1.0, sumsq_next=None):
+    """sumsq (device scalar) switches the device-side clip: scale = min(1, max_norm / (sqrt(sumsq) * post + 1e-6)) * post."""
     _lib.check(_lib.lib().vl_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(seg_end),
                                    _p(seg_lr), _p(seg_wd), seg_end.numel(), float(beta1), float(beta2), float(eps),
                                    int(step), int(bool(correct_bias)), float(lr_mult), _p(grad_scale_dev),
-                                   float(grad_scale), int(bool(zero_grad)), _p(row_flags), flag_begin, flag_rows,
+                                   float(grad_scale), _p(sumsq), float(max_norm), float(post), _p(sumsq_next),
+                                   int(bool(zero_grad)), _p(row_flags), flag_begin, flag_rows,
                                    flag_row_len, _stream()), "vl_adamw")
 
 

@@ -184,11 +184,12 @@ class FusedAdamW(object):
         self.warmup_steps, self.t_total = warmup_steps, t_total
         self.sched_step = 0  # scheduler.step() count (train_task.py:335)
         self.opt_step = 0
-        self._sumsq = torch.zeros(1, dtype=torch.float32, device=device)
-        self._scale = torch.zeros(1, dtype=torch.float32, device=device)
+        self._sumsq = torch.zeros(2, dtype=torch.float32, device=device)  # two accumulators alternate: AdamW zeroes the next
+        self.return_norm = False  # step() returns the gradient norm tensor (one extra tiny launch) only on request
         if hasattr(model, "mark_weights_dirty"):
             model.mark_weights_dirty()
         self._active, self._sink_index, self.row_flags = None, -1, None
+        self._planned, self._loose = frozenset(), None
         eng = getattr(model, "engine", None)
         if eng is not None:  # scatter the word-embedding gradient straight into the (zeroed) arena
             emb = model.bert.embeddings.word_embeddings if hasattr(model.bert, "embeddings") else model.bert.encoder.embeddings
@@ -233,6 +234,10 @@ class FusedAdamW(object):
                 ranges.append((lo, hi))
                 plan.append((idx, [self.arena.grad_views[i] for i in idx], ranges))
             self._layer_plan = plan
+            # steady state of a training step: every planned layer gradient arrives through the sinks; only the `loose`
+            # parameters (embeddings, pooler, classifier) still come from autograd
+            self._planned = frozenset(i for pl in plan if pl is not None for i in pl[0])
+            self._loose = [i for i in range(len(self.groups)) if i not in self._planned]
             eng.stack.layer_done_hook = self._on_layer_grads
             eng.stack.grad_sink = self._sink_for_layer
 
@@ -285,6 +290,7 @@ class FusedAdamW(object):
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.opt_step, self.sched_step = int(sd["opt_step"]), int(sd["sched_step"])
+        self._sumsq.zero_()  # (the accumulator in use alternates with the parity of opt_step)
         if self.row_flags is not None:
             if sd.get("row_flags") is not None:
                 self.row_flags.copy_(sd["row_flags"])
@@ -330,14 +336,35 @@ class FusedAdamW(object):
         """reduce -> clip -> AdamW -> scheduler step -> zero_grad  (train_task.py:326-338)."""
         a = self.arena
         pre = self._pre
-        has = a.gather_grads(pre)
+        if self._loose is not None and len(pre) == len(self._planned) and pre == self._planned:
+            # fast path (no walk over the 215 groups): the planned layer gradients sit in the arena already
+            dst, src, has_loose = [], [], []
+            for i in self._loose:
+                g = self.groups[i][1].grad
+                has_loose.append(g is not None)
+                if g is not None:
+                    dst.append(a.grad_views[i])
+                    src.append(g)
+                    self.groups[i][1].grad = None
+            if dst:
+                torch._foreach_copy_(dst, src)
+            akey = ("fast", tuple(has_loose))
+            if akey != self._active:
+                hl = dict(zip(self._loose, has_loose))
+                has = [True if i in self._planned else hl[i] for i in range(len(self.groups))]
+            else:
+                has = None
+        else:
+            has = a.gather_grads(pre)
+            akey = ("slow", tuple(has))
         # parameters that received no gradient are skipped entirely, like `if p.grad is None: continue` in
         # pytorch_transformers.AdamW (no moment decay, no weight decay): M3P's 93 M never-used parameters
-        active = tuple(h or (i == self._sink_index) for i, h in enumerate(has))
-        if active != self._active:
-            self._active = active
+        if akey != self._active:
+            self._active = akey
+            self._active_list = active = tuple(h or (i == self._sink_index) for i, h in enumerate(has))
             lr = [g[2] if act else 0.0 for g, act in zip(self.groups, active)]
             self.seg_lr.copy_(torch.tensor(lr, dtype=torch.float32))
+        active = self._active_list
         eng = getattr(self.model, "engine", None)
         skip = None
         if eng is not None and eng.pending_word_grad is not None:  # multi-GPU sparse path
@@ -376,17 +403,17 @@ class FusedAdamW(object):
         self._pre = set()
         if self.keep_reduced_grad:  # tests: the summed gradient and the 1/world factor the kernels apply to it
             self.last_reduced_grad, self.last_post = a.grad.clone(), post
-        self._sumsq.zero_()
-        # (table rows that never received a gradient are exact zeros: not read)
-        ops.sumsq(a.grad, self._sumsq, **(self._flag_args() if self.flag_sumsq else {}))
-        # clip coefficient on the device: min(1, max_norm / (||g|| + 1e-6)) with ||g|| of the averaged gradient
-        norm = self._sumsq.sqrt() * post
-        torch.clamp(self.max_grad_norm / (norm + 1e-6), max=1.0, out=self._scale)
-        self._scale.mul_(post)
+        # sum(g^2) into this step's accumulator (zeroed by the previous step's AdamW launch; table rows that never
+        # received a gradient are exact zeros: not read); the clip coefficient min(1, max_norm / (||g|| + 1e-6)) with
+        # ||g|| of the averaged gradient is computed by the AdamW kernel itself -- no scalar glue kernels in between
+        cur, nxt = self._sumsq[self.opt_step % 2:self.opt_step % 2 + 1], self._sumsq[(self.opt_step + 1) % 2:(self.opt_step + 1) % 2 + 1]
+        ops.sumsq(a.grad, cur, **(self._flag_args() if self.flag_sumsq else {}))
+        norm = (cur.sqrt() * post) if self.return_norm else None
         self.opt_step += 1
+        max_norm = self.max_grad_norm if self.max_grad_norm is not None else float("inf")
         ops.adamw(a.param, a.grad, self.exp_avg, self.exp_avg_sq, self.seg_end, self.seg_lr, self.seg_wd,
                   self.betas[0], self.betas[1], self.eps, self.opt_step, self.correct_bias, self.lr_mult(),
-                  grad_scale_dev=self._scale, zero_grad=True, **self._flag_args())
+                  sumsq=cur, max_norm=min(max_norm, 3.0e38), post=post, sumsq_next=nxt, zero_grad=True, **self._flag_args())
         self.sched_step += 1
         if hasattr(self.model, "mark_weights_dirty"):
             self.model.mark_weights_dirty()

@@ -28,6 +28,29 @@ def compute_score_with_logits(logits, labels):
     return one_hots * labels
 
 
+class GQALossFunction(torch.autograd.Function):
+    """loss, score = GQA loss with semantic prior (task_utils.py:413-428) through vl_gqa_loss: one launch computes the
+    loss, the batch score and d(loss)/d(logits); backward only scales the saved gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, target, distances, semantic_lambda):
+        from . import _lib, ops
+        B = logits.shape[0]
+        logits = logits.contiguous()
+        out = torch.empty(2, dtype=torch.float32, device=logits.device)
+        dlogits = torch.empty_like(logits)
+        ws = torch.empty(_lib.lib().vl_gqa_loss_ws_bytes(B), dtype=torch.uint8, device=logits.device)
+        ops.gqa_loss(logits, target.contiguous().float(), distances.contiguous().float(), semantic_lambda, out, dlogits, ws)
+        ctx.save_for_backward(dlogits)
+        ctx.mark_non_differentiable(out[1])
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, g_score):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g_loss, None, None, None
+
+
 def _to_device(batch, device):
     return tuple(t.to(device=device, non_blocking=True) for t in batch)
 
@@ -40,7 +63,13 @@ def ForwardModelsTrain(config, task_cfg, device, task_id, batch, model, criterio
     batch_size = features.size(0)
     ttype = task_cfg[task_id]["type"]
     vil_prediction = model(question, features, spatials, task_id, segment_ids, input_mask, image_mask)[0]
-    if ttype == "VL-classifier-GQA":
+    plain_ce = type(criterion) is nn.CrossEntropyLoss and criterion.reduction == "mean" and criterion.weight is None \
+        and criterion.ignore_index == -100 and getattr(criterion, "label_smoothing", 0.0) == 0.0
+    if ttype == "VL-classifier-GQA" and plain_ce and vil_prediction.is_cuda and vil_prediction.dtype == torch.float32 \
+            and vil_prediction.shape[1] <= 4096:
+        # the reference's arithmetic (the branch below) as one native launch: loss, score and d(loss)/d(logits)
+        loss, batch_score = GQALossFunction.apply(vil_prediction, target, distances, float(task_cfg[task_id]["semantic_lambda"]))
+    elif ttype == "VL-classifier-GQA":
         semantic_lambda = task_cfg[task_id]["semantic_lambda"]
         p_top_k, idx_top_k = torch.topk(F.softmax(vil_prediction, dim=-1), k=10)
         semantic_loss = p_top_k * distances[torch.arange(distances.size(0), device=distances.device).unsqueeze(1),

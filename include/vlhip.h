@@ -101,7 +101,7 @@ int vl_gemm_tn_grouped(const int64_t* probs, int64_t nprob, int64_t K, int64_t s
 #define VL_TR_FIELDS 6
 #define VL_DW_FIELDS 10
 int64_t vl_blocked_elems(int64_t M, int64_t N);
-int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, void* stream);
+int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, int64_t max_blocks /* 0 = default (4096) */, void* stream);
 int vl_colsum_finalize(const float* partial, int64_t nblk, int64_t N, float* const* outs, int64_t nout, int accumulate,
                        void* stream);
 int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream);
@@ -242,6 +242,8 @@ enum {
   VL_ST_PROF = 25, /* HOST pointer to a VlProf block (0 = no timing), see below */
   VL_ST_POOLED_ONLY = 26, /* != 0: only row 0 of every sample of the LAST layer's output is live (see below) */
   VL_ST_ROWS0 = 27, /* int64 [B] device array {0, S, 2S, ...}: the live rows (pooled-row mode) */
+  VL_ST_TR_BLOCKS_FWD = 28, /* workgroup caps of the K-major re-layout launches (0 = default) */
+  VL_ST_TR_BLOCKS_BWD = 29,
   VL_ST_FIELDS = 32
 };
 enum {
@@ -385,6 +387,19 @@ int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db,
                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * GQA loss with semantic prior, its score and d(loss)/d(logits) in one launch (csrc/loss.hip).
+ * Replaces the ~45 eager kernels of task_utils.py:413-428 + compute_score_with_logits (:706-711):
+ *   p = softmax(logits); (p10, idx) = topk(p, 10); prior = mean_b sum_k p10 * distances[b, idx];
+ *   loss = CE(logits, argmax(target.long())) * C + semantic_lambda * prior * C;  score = sum_b target[b, argmax logits_b] / B.
+ * logits / target / distances / dlogits: [B, C] fp32 (C <= 4096); loss_score: 2 floats {loss, score}; ws: >=
+ * vl_gqa_loss_ws_bytes(B) bytes of scratch.
+ * dlogits = d(loss)/d(logits) for upstream gradient 1 (top-k indices are constants for autograd, as in torch).
+ * ------------------------------------------------------------------------------------------------------------ */
+int64_t vl_gqa_loss_ws_bytes(int64_t B);
+int vl_gqa_loss(const float* logits, const float* target, const float* distances, int64_t B, int64_t C,
+                float semantic_lambda, float* loss_score, float* dlogits, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Fused optimizer step over a flat parameter arena (next-row f1 of SURVEY.md section 8):
  * AdamW as pytorch_transformers.optimization.AdamW (call site train_task.py:264-268): bias-corrected step size,
  * decoupled weight decay applied after the Adam update; grads pre-scaled by *grad_scale_dev (device scalar, e.g. the
@@ -392,6 +407,10 @@ int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db,
  * segment i in the arena, seg_lr / seg_wd its base lr and weight decay (215 one-tensor param groups,
  * train_task.py:249-260); `lr_mult` = the LR schedule's multiplier for this step (WarmupLinearSchedule,
  * train_task.py:274).  `step` = 1-based optimizer step.  Also zeroes the gradient when zero_grad != 0.
+ * sumsq_dev (may be NULL): device scalar sum(g^2) (vl_sumsq): the kernel then computes the clip_grad_norm_ coefficient
+ * itself, grad scale = min(1, max_norm / (sqrt(sumsq) * post + 1e-6)) * post (post = 1/world_size of the all-reduce),
+ * overriding grad_scale_dev / grad_scale; sumsq_next (may be NULL) = ANOTHER device scalar that is set to 0 (the next
+ * step's accumulator: two alternate, so no separate fill launch is needed).
  * row_flags (may be NULL): per-row "has ever received a gradient" bytes for the table occupying arena elements
  * [flag_begin, flag_begin + flag_rows*flag_row_len): rows with flag 0 have g = m = v = 0, so only p *= (1 - lr*wd)
  * is applied (8 B/param of traffic instead of 32; bit-identical to the dense update).
@@ -399,6 +418,7 @@ int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db,
 int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const int64_t* seg_end,
              const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1, float beta2, float eps,
              int64_t step, int correct_bias, float lr_mult, const float* grad_scale_dev, float grad_scale,
+             const float* sumsq_dev, float max_norm, float post, float* sumsq_next,
              int zero_grad, const uint8_t* row_flags, int64_t flag_begin, int64_t flag_rows, int64_t flag_row_len,
              void* stream);
 /* out[0] += sum(x^2) over n floats (atomic; zero out[0] first). */

@@ -749,3 +749,37 @@ def test_colreduce_multi_matches_fp64_and_accumulates():
     first = torch.cat(oa).clone()
     ops.colreduce_multi([(a, 768, oa)], accumulate=True)
     assert torch.equal(torch.cat(oa), first + first)
+
+
+@pytest.mark.parametrize("B,C", [(256, 1842), (4, 1842), (7, 300), (3, 4096)])
+def test_gqa_loss_kernel_matches_the_reference_arithmetic(B, C):
+    """vl_gqa_loss against the eager arithmetic of task_utils.py:413-428 + :706-711 (torch autograd for the gradient)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B + C)
+    logits = (torch.randn(B, C, generator=g) * 2.0).to(DEV)
+    labels = torch.randint(0, C, (B,), generator=g)
+    target = torch.zeros(B, C)
+    target[torch.arange(B), labels] = 1.0
+    target[0, labels[0]] = 0.5  # a fractional score: .long() truncates it to 0 -> label 0 for that row, like the reference
+    dist = torch.rand(B, C, generator=g)
+    dist[torch.arange(B), labels] = 0.0
+    # make half of the rows "correct" so that the score is not trivially zero
+    for b in range(0, B, 2):
+        logits[b, labels[b]] = 50.0
+    target, dist = target.to(DEV), dist.to(DEV)
+    lam = 10.0
+    z = logits.double().clone().requires_grad_(True)
+    p10, idx = torch.topk(F.softmax(z, dim=-1), k=min(10, C))
+    sem = torch.mean(torch.sum(p10 * dist.double()[torch.arange(B, device=DEV).unsqueeze(1), idx], dim=-1), dim=0)
+    ref = F.cross_entropy(z, torch.argmax(target.long(), dim=1)).mean() * C + (lam * sem.mean()) * C
+    ref.backward()
+    oh = torch.zeros_like(target)
+    oh.scatter_(1, logits.argmax(1, keepdim=True), 1)
+    ref_score = (oh * target).sum() / B
+    out = torch.empty(2, device=DEV)
+    dl = torch.full((B, C), float("nan"), device=DEV)
+    ws = torch.empty(ops._lib.lib().vl_gqa_loss_ws_bytes(B), dtype=torch.uint8, device=DEV)
+    ops.gqa_loss(logits, target, dist, lam, out, dl, ws)
+    assert abs(out[0].item() - ref.item()) <= 2e-6 * abs(ref.item()), (out[0].item(), ref.item())
+    assert out[1].item() == ref_score.item()
+    torch.testing.assert_close(dl.double(), z.grad, rtol=2e-5, atol=2e-5 * z.grad.abs().max().item())

@@ -42,6 +42,7 @@ def test_training_trajectory_follows_the_fp32_reference(n_layers, n_steps, grad_
     hp = dict(base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True, warmup_steps=2,
               t_total=20, max_grad_norm=1.0)  # experiments/zero_shot/uc2/xgqa/train.dtu.sh:20-28; short schedule
     opt = FusedAdamW(model, overlap_reduce=None if grad_acc == 1 else False, **hp)
+    opt.return_norm = True
     ref = A.ReferenceAdamW(oracle.named_parameters(), **hp)
     batches = [make_batch(8, vocab_size=2000, seed=900 + i) for i in range(4)]
     crit = torch.nn.CrossEntropyLoss()

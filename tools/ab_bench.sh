@@ -1,5 +1,5 @@
-# A/B of kernel variants inside one box / one device.  AB_CONFIGS: space-separated "ENV=VAL[,ENV=VAL]" settings.
-for cfg in ${AB_CONFIGS:-"VL_DEBUG=7:0" "VL_DEBUG=7:1"}; do
+# A/B of variants inside one box / one device.  AB_CONFIGS: space-separated "ENV=VAL[,ENV=VAL]" settings.
+for cfg in ${AB_CONFIGS:-"X=0"}; do
   echo "== $cfg"
-  env $(echo $cfg | tr ',' ' ') timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | grep -E "gpu part|rror"
+  env $(echo $cfg | tr ';' ' ') timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>&1 | grep -E "gpu part|rror"
 done
