@@ -28,6 +28,9 @@ def compute_score_with_logits(logits, labels):
     return one_hots * labels
 
 
+FUSED_GQA_LOSS = True  # A/B knob (bench.py BENCH_TORCH_LOSS=1): False = the eager torch arithmetic below
+
+
 class GQALossFunction(torch.autograd.Function):
     """loss, score = GQA loss with semantic prior (task_utils.py:413-428) through vl_gqa_loss: one launch computes the
     loss, the batch score and d(loss)/d(logits); backward only scales the saved gradient."""
@@ -66,7 +69,7 @@ def ForwardModelsTrain(config, task_cfg, device, task_id, batch, model, criterio
     plain_ce = type(criterion) is nn.CrossEntropyLoss and criterion.reduction == "mean" and criterion.weight is None \
         and criterion.ignore_index == -100 and getattr(criterion, "label_smoothing", 0.0) == 0.0
     if ttype == "VL-classifier-GQA" and plain_ce and vil_prediction.is_cuda and vil_prediction.dtype == torch.float32 \
-            and vil_prediction.shape[1] <= 4096:
+            and vil_prediction.shape[1] <= 4096 and FUSED_GQA_LOSS:
         # the reference's arithmetic (the branch below) as one native launch: loss, score and d(loss)/d(logits)
         loss, batch_score = GQALossFunction.apply(vil_prediction, target, distances, float(task_cfg[task_id]["semantic_lambda"]))
     elif ttype == "VL-classifier-GQA":
