@@ -30,8 +30,9 @@
 
 namespace {
 
-constexpr int DH = 64;
-constexpr int PITCH = 144;  // bytes per [row][64] bf16 LDS row
+// head dim DH (64: the model configs; 32: the tiny "c1" plumbing config) is a template parameter: KS = DH / 32 k-steps
+// per Q.K^T product, DT = DH / 16 output column tiles, LDS row pitch DH * 2 + 16 bytes
+template <int DH> struct Geo { static constexpr int KS = DH / 32, DT = DH / 16, PITCH = DH * 2 + 16; };
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -93,10 +94,12 @@ __device__ __forceinline__ float keep_of(const Attn2Args& p, unsigned bits, int 
   return u >= p.thr16 ? p.inv_keep : 0.0f;
 }
 
-// stage rows [0, Spad) x 64 bf16 of one matrix into an LDS tile (zeros beyond `rows`); src row pitch ld elements
+// stage rows [0, Spad) x DH bf16 of one matrix into an LDS tile (zeros beyond `rows`); src row pitch ld elements
+template <int DH>
 __device__ __forceinline__ void stage16(unsigned char* dst, const bf16_raw* src, long ld, int rows, int Spad, int tid) {
-  for (int idx = tid; idx < Spad * 8; idx += 256) {
-    const int row = idx >> 3, c = idx & 7;
+  constexpr int CH = DH / 8, PITCH = Geo<DH>::PITCH;  // 16-byte chunks per row
+  for (int idx = tid; idx < Spad * CH; idx += 256) {
+    const int row = idx / CH, c = idx - row * CH;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (row < rows) v = *reinterpret_cast<const uint4*>(src + (long)row * ld + c * 8);
     *reinterpret_cast<uint4*>(dst + row * PITCH + c * 16) = v;
@@ -106,10 +109,11 @@ __device__ __forceinline__ void stage16(unsigned char* dst, const bf16_raw* src,
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int DH>
 __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int Spad = NT * 16, NP = (NT + 1) / 2;  // key-tile pairs
+  constexpr int KS = Geo<DH>::KS, DT = Geo<DH>::DT, PITCH = Geo<DH>::PITCH;
   unsigned char* sKh = sm;
   unsigned char* sKl = sKh + Spad * PITCH;
   unsigned char* sVh = sKl + Spad * PITCH;
@@ -121,10 +125,10 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
   const long ld = 3L * p.H;
   const bf16_raw* bh = p.qkv_hi + (long)b * S * ld + h * DH;
   const bf16_raw* bl = p.qkv_lo + (long)b * S * ld + h * DH;
-  stage16(sKh, bh + p.H, ld, S, Spad, tid);
-  stage16(sKl, bl + p.H, ld, S, Spad, tid);
-  stage16(sVh, bh + 2 * p.H, ld, S, Spad, tid);
-  stage16(sVl, bl + 2 * p.H, ld, S, Spad, tid);
+  stage16<DH>(sKh, bh + p.H, ld, S, Spad, tid);
+  stage16<DH>(sKl, bl + p.H, ld, S, Spad, tid);
+  stage16<DH>(sVh, bh + 2 * p.H, ld, S, Spad, tid);
+  stage16<DH>(sVl, bl + 2 * p.H, ld, S, Spad, tid);
   for (int k = tid; k < Spad; k += 256) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
   const int l15 = lane & 15, g = lane >> 4, qq = l15 >> 2, pp = lane & 3;
   const int nqt = (p.nq + 15) >> 4;
@@ -133,9 +137,9 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
   for (int qt = wave; qt < nqt; qt += 4) {
     const int q = qt * 16 + l15;
     // this lane's query row as the B operand of S^T = K.Q^T: Q[q][32 ks + 8 g ..]
-    bf16x8 qh[2], ql[2];
+    bf16x8 qh[KS], ql[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       uint4 vh = make_uint4(0u, 0u, 0u, 0u), vl = vh;
       if (q < S) {
         vh = *reinterpret_cast<const uint4*>(bh + (long)q * ld + 32 * ks + 8 * g);
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
       sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       const int off = (t * 16 + l15) * PITCH + 16 * g;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         const bf16x8 kh = lds_frag(sKh + off + 64 * ks), kl = lds_frag(sKl + off + 64 * ks);
         sc[t] = mfma(kh, ql[ks], sc[t]);
         sc[t] = mfma(kl, qh[ks], sc[t]);
@@ -192,9 +196,9 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
       sc[t][0] *= inv * k0; sc[t][1] *= inv * k1; sc[t][2] *= inv * k2; sc[t][3] *= inv * k3;
     }
     // ctx^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
-    f32x4 o[4];
+    f32x4 o[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
       const int t0 = 2 * pr, t1 = 2 * pr + 1;
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
       const int r0 = (16 * t0 + 4 * g + qq) * PITCH + 8 * pp;
       const int r1 = (16 * (t1 < NT ? t1 : t0) + 4 * g + qq) * PITCH + 8 * pp;  // (the slots of a missing tile hold p = 0)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < DT; ++dt) {
         const bf16x8 vh = tr_frag2(sVh + r0 + 32 * dt, sVh + r1 + 32 * dt);
         const bf16x8 vl = tr_frag2(sVl + r0 + 32 * dt, sVl + r1 + 32 * dt);
         o[dt] = mfma(vh, pl, o[dt]);
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
     if (q < p.nq) {
       const long orow = (long)b * p.ctx_rows + q;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < DT; ++dt) {
         ushort4 hi, lo;
         split_bf16(o[dt][0], hi.x, lo.x); split_bf16(o[dt][1], hi.y, lo.y);
         split_bf16(o[dt][2], hi.z, lo.z); split_bf16(o[dt][3], hi.w, lo.w);
@@ -238,10 +242,11 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
 // Phase A (a wave owns query tiles, transposed layout): delta and dQ.  Phase B (a wave owns key tiles, plain layout,
 // scores recomputed): dK and dV accumulate in registers over the query tiles.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int DH>
 __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int Spad = NT * 16, NP = (NT + 1) / 2;
+  constexpr int KS = Geo<DH>::KS, DT = Geo<DH>::DT, PITCH = Geo<DH>::PITCH;
   unsigned char* sQ = sm;
   unsigned char* sK = sQ + Spad * PITCH;
   unsigned char* sV = sK + Spad * PITCH;
@@ -254,10 +259,10 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
   const int S = p.S;
   const long ld = 3L * p.H;
   const bf16_raw* bh = p.qkv_hi + (long)b * S * ld + h * DH;
-  stage16(sQ, bh, ld, S, Spad, tid);
-  stage16(sK, bh + p.H, ld, S, Spad, tid);
-  stage16(sV, bh + 2 * p.H, ld, S, Spad, tid);
-  stage16(sO, p.dctx + (long)b * p.ctx_rows * p.H + h * DH, p.H, p.nq, Spad, tid);
+  stage16<DH>(sQ, bh, ld, S, Spad, tid);
+  stage16<DH>(sK, bh + p.H, ld, S, Spad, tid);
+  stage16<DH>(sV, bh + 2 * p.H, ld, S, Spad, tid);
+  stage16<DH>(sO, p.dctx + (long)b * p.ctx_rows * p.H + h * DH, p.H, p.nq, Spad, tid);
   for (int k = tid; k < Spad; k += 256) {
     smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
     slse[k] = k < S ? p.lse[((long)b * p.nh + h) * S + k] : INFINITY;  // +inf -> P = 0 for padded queries
@@ -276,14 +281,14 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
     if (qt >= nqt) {  // rows without a gradient: dQ = 0
       if (q < S) {
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+        for (int dt = 0; dt < DT; ++dt)
           *reinterpret_cast<ushort4*>(dq_base + (long)q * ld + 16 * dt + 4 * g) = make_ushort4(0, 0, 0, 0);
       }
       continue;
     }
-    bf16x8 fq[2], fo[2];
+    bf16x8 fq[KS], fo[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       fq[ks] = lds_frag(sQ + q * PITCH + 16 * g + 64 * ks);
       fo[ks] = lds_frag(sO + q * PITCH + 16 * g + 64 * ks);
     }
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
       const int off = (t * 16 + l15) * PITCH + 16 * g;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         s = mfma(lds_frag(sK + off + 64 * ks), fq[ks], s);
         dp = mfma(lds_frag(sV + off + 64 * ks), fo[ks], dp);
       }
@@ -319,9 +324,9 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
     if (g == 0) sdelta[q] = delta;
-    f32x4 o[4];
+    f32x4 o[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
       const int t0 = 2 * pr, t1 = (2 * pr + 1 < NT) ? 2 * pr + 1 : 2 * pr;
@@ -336,11 +341,11 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
       const int r0 = (16 * t0 + 4 * g + qq) * PITCH + 8 * pp;
       const int r1 = (16 * t1 + 4 * g + qq) * PITCH + 8 * pp;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = mfma(tr_frag2(sK + r0 + 32 * dt, sK + r1 + 32 * dt), dsb, o[dt]);
+      for (int dt = 0; dt < DT; ++dt) o[dt] = mfma(tr_frag2(sK + r0 + 32 * dt, sK + r1 + 32 * dt), dsb, o[dt]);
     }
     if (q < S) {
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < DT; ++dt) {
         ushort4 v;
         v.x = f32_to_bf16(o[dt][0]); v.y = f32_to_bf16(o[dt][1]); v.z = f32_to_bf16(o[dt][2]); v.w = f32_to_bf16(o[dt][3]);
         *reinterpret_cast<ushort4*>(dq_base + (long)q * ld + 16 * dt + 4 * g) = v;
@@ -353,16 +358,16 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
   const int nqp = (nqt + 1) >> 1;  // query-tile pairs
   for (int kt = wave; kt < NT; kt += 4) {
     const int key = kt * 16 + l15;
-    bf16x8 fk[2], fv[2];
+    bf16x8 fk[KS], fv[KS];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       fk[ks] = lds_frag(sK + key * PITCH + 16 * g + 64 * ks);
       fv[ks] = lds_frag(sV + key * PITCH + 16 * g + 64 * ks);
     }
     const float mk = smask[key];
-    f32x4 dK[4], dV[4];
+    f32x4 dK[DT], dV[DT];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int dt = 0; dt < DT; ++dt) { dK[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     for (int pq = 0; pq < nqp; ++pq) {
       float pdv[8], dsv[8];
 #pragma unroll
@@ -372,7 +377,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
           f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
           const int off = (qt * 16 + l15) * PITCH + 16 * g;
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
+          for (int ks = 0; ks < KS; ++ks) {
             s = mfma(lds_frag(sQ + off + 64 * ks), fk[ks], s);
             dp = mfma(lds_frag(sO + off + 64 * ks), fv[ks], dp);
           }
@@ -395,7 +400,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
       const int r0 = (32 * pq + 4 * g + qq) * PITCH + 8 * pp;
       const int r1 = (16 * qt1 + 4 * g + qq) * PITCH + 8 * pp;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < DT; ++dt) {
         dV[dt] = mfma(tr_frag2(sO + r0 + 32 * dt, sO + r1 + 32 * dt), bpd, dV[dt]);
         dK[dt] = mfma(tr_frag2(sQ + r0 + 32 * dt, sQ + r1 + 32 * dt), bds, dK[dt]);
       }
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
     if (key < S) {
       bf16_raw* out = p.dqkv + ((long)b * S + key) * ld + h * DH;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < DT; ++dt) {
         ushort4 a, c;
         a.x = f32_to_bf16(dK[dt][0]); a.y = f32_to_bf16(dK[dt][1]); a.z = f32_to_bf16(dK[dt][2]); a.w = f32_to_bf16(dK[dt][3]);
         c.x = f32_to_bf16(dV[dt][0]); c.y = f32_to_bf16(dV[dt][1]); c.z = f32_to_bf16(dV[dt][2]); c.w = f32_to_bf16(dV[dt][3]);
@@ -414,39 +419,48 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
   }
 }
 
-inline size_t fwd_lds(int NT) { return (size_t)NT * 16 * (4 * PITCH + 4); }
-inline size_t bwd_lds(int NT) { return (size_t)NT * 16 * (4 * PITCH + 12); }
-
-template <int NT>
+template <int NT, int DH>
 int launch_fwd(const Attn2Args& a, hipStream_t s) {
-  const size_t lds = fwd_lds(NT);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<NT>),
+  const size_t lds = (size_t)NT * 16 * (4 * Geo<DH>::PITCH + 4);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<NT, DH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return vl_set_error(-3, "vl_attn2_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((attn2_fwd_kernel<NT>), dim3(a.B * a.nh), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn2_fwd_kernel<NT, DH>), dim3(a.B * a.nh), dim3(256), lds, s, a);
   VL_CHECK_LAUNCH("vl_attn2_fwd");
   return 0;
 }
-template <int NT>
+template <int NT, int DH>
 int launch_bwd(const Attn2Args& a, hipStream_t s) {
-  const size_t lds = bwd_lds(NT);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_kernel<NT>),
+  const size_t lds = (size_t)NT * 16 * (4 * Geo<DH>::PITCH + 12);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_kernel<NT, DH>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return vl_set_error(-3, "vl_attn2_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((attn2_bwd_kernel<NT>), dim3(a.B * a.nh), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn2_bwd_kernel<NT, DH>), dim3(a.B * a.nh), dim3(256), lds, s, a);
   VL_CHECK_LAUNCH("vl_attn2_bwd");
   return 0;
+}
+template <int DH> int dispatch_fwd(const Attn2Args& a, hipStream_t s) {
+  if (a.S <= 64) return launch_fwd<4, DH>(a, s);
+  if (a.S <= 80) return launch_fwd<5, DH>(a, s);
+  if (a.S <= 128) return launch_fwd<8, DH>(a, s);
+  return launch_fwd<10, DH>(a, s);
+}
+template <int DH> int dispatch_bwd(const Attn2Args& a, hipStream_t s) {
+  if (a.S <= 64) return launch_bwd<4, DH>(a, s);
+  if (a.S <= 80) return launch_bwd<5, DH>(a, s);
+  if (a.S <= 128) return launch_bwd<8, DH>(a, s);
+  return launch_bwd<10, DH>(a, s);
 }
 
 int fill_common(const char* fn, Attn2Args& a, int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop,
                 uint64_t seed) {
-  VL_CHECK_ARG(dh == DH, "%s: head dim must be 64 (got %lld)", fn, (long long)dh);
+  VL_CHECK_ARG(dh == 64 || dh == 32, "%s: head dim must be 64 or 32 (got %lld)", fn, (long long)dh);
   VL_CHECK_ARG(S >= 1 && S <= 160, "%s: sequence length T+V must be in [1,160] (got %lld)", fn, (long long)S);
   VL_CHECK_ARG(B >= 1 && nh >= 1 && B * nh < (1LL << 30) && B * nh * S < (1LL << 31), "%s: bad B=%lld nh=%lld", fn,
                (long long)B, (long long)nh);
   VL_CHECK_ARG(nq >= 1 && nq <= S, "%s: nq must be in [1, S] (got %lld)", fn, (long long)nq);
   VL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: dropout p must be in [0,1)", fn);
-  a.B = (int)B; a.S = (int)S; a.nh = (int)nh; a.H = (int)(nh * DH); a.nq = (int)nq; a.ctx_rows = (int)nq;
+  a.B = (int)B; a.S = (int)S; a.nh = (int)nh; a.H = (int)(nh * dh); a.nq = (int)nq; a.ctx_rows = (int)nq;
   a.scale = 1.0f / sqrtf((float)dh); a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop);
   a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32) * 0x85ebca6bu + 0x27d4eb2fu;
   a.thr16 = (unsigned)(p_drop * 65536.0f + 0.5f);
@@ -466,10 +480,7 @@ extern "C" int vl_attn2_fwd(const void* qkv_hi, const void* qkv_lo, const float*
   a.qkv_hi = (const bf16_raw*)qkv_hi; a.qkv_lo = (const bf16_raw*)qkv_lo; a.addmask = addmask;
   a.ctx_hi = (bf16_raw*)ctx_hi; a.ctx_lo = (bf16_raw*)ctx_lo; a.lse = lse;
   hipStream_t s = (hipStream_t)stream;
-  if (S <= 64) return launch_fwd<4>(a, s);
-  if (S <= 80) return launch_fwd<5>(a, s);
-  if (S <= 128) return launch_fwd<8>(a, s);
-  return launch_fwd<10>(a, s);
+  return dh == 64 ? dispatch_fwd<64>(a, s) : dispatch_fwd<32>(a, s);
 }
 
 extern "C" int vl_attn2_bwd(const void* qkv_hi, const float* addmask, const void* dctx16, const float* lse,
@@ -482,8 +493,5 @@ extern "C" int vl_attn2_bwd(const void* qkv_hi, const float* addmask, const void
   a.qkv_hi = (const bf16_raw*)qkv_hi; a.addmask = addmask; a.dctx = (const bf16_raw*)dctx16;
   a.lse = const_cast<float*>(lse); a.dqkv = (bf16_raw*)dqkv16;
   hipStream_t s = (hipStream_t)stream;
-  if (S <= 64) return launch_bwd<4>(a, s);
-  if (S <= 80) return launch_bwd<5>(a, s);
-  if (S <= 128) return launch_bwd<8>(a, s);
-  return launch_bwd<10>(a, s);
+  return dh == 64 ? dispatch_bwd<64>(a, s) : dispatch_bwd<32>(a, s);
 }

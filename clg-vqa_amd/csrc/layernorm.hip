@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
+      if (c >= p.H) { z[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }  // H = 128: half of the wave is idle
       const long e = r * p.H + c;
       const long eo_ = r * p.orig_stride * p.H + c;  // element index in the full problem (dropout counter)
       float4 v = *reinterpret_cast<const float4*>(p.y + e);
@@ -75,6 +76,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+      if ((i * 64 + lane) * 4 >= p.H) continue;
       const float a = z[i].x - mu, b = z[i].y - mu, c = z[i].z - mu, d = z[i].w - mu;
       ss += (a * a + b * b) + (c * c + d * d);
     }
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
+      if (c >= p.H) continue;
       const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
       const float4 bt = *reinterpret_cast<const float4*>(p.beta + c);
       float4 o;
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
+        if (c >= p.H) { dy[k][i] = zz[k][i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
         dy[k][i] = *reinterpret_cast<const float4*>(p.dy + orow[k] * p.H + c);
         zz[k][i] = *reinterpret_cast<const float4*>(p.z + rr[k] * p.H + c);
       }
@@ -153,6 +157,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
+        if (c >= p.H) { xh[i] = make_float4(0.f, 0.f, 0.f, 0.f); continue; }
         const long e = r * p.orig_stride * p.H + c;
         float4 d = dy[k][i];
         if (p.p_post > 0.f) {
@@ -179,6 +184,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
         const int c = (i * 64 + lane) * 4;
+        if (c >= p.H) continue;
         const long e = r * p.H + c;
         float4 dz;
         dz.x = (dy[k][i].x - c1 - xh[i].x * c2) * rs;
@@ -276,8 +282,8 @@ int launch_bwd(const LnArgs& a, hipStream_t s, float* dgamma, float* dbeta, floa
 }
 
 int check_shape(const char* fn, int64_t M, int64_t H, int64_t group, float p_pre, float p_post) {
-  VL_CHECK_ARG(M > 0 && H > 0 && H % 256 == 0 && H <= 2048 && (H / 256 <= 4 || H == 1536 || H == 2048),
-               "%s: H must be 256,512,768,1024,1536 or 2048 (got %lld)", fn, (long long)H);
+  VL_CHECK_ARG(M > 0 && H > 0 && (H == 128 || (H % 256 == 0 && H <= 2048 && (H / 256 <= 4 || H == 1536 || H == 2048))),
+               "%s: H must be 128,256,512,768,1024,1536 or 2048 (got %lld)", fn, (long long)H);
   VL_CHECK_ARG(group > 0, "%s: group must be > 0", fn);
   VL_CHECK_ARG(p_pre >= 0.f && p_pre < 1.f && p_post >= 0.f && p_post < 1.f, "%s: dropout p must be in [0,1)", fn);
   return 0;
@@ -303,7 +309,7 @@ extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addv
   VL_CHECK_ARG(orig_row_stride >= 1 && resid_row_stride >= 1, "vl_ln_fwd: row strides must be >= 1");
   a.orig_stride = orig_row_stride; a.resid_stride = resid_row_stride;
   hipStream_t s = (hipStream_t)stream;
-  switch (H / 256) {
+  switch ((H + 255) / 256) {
     case 1: return launch_fwd<1>(a, s);
     case 2: return launch_fwd<2>(a, s);
     case 3: return launch_fwd<3>(a, s);
@@ -332,7 +338,7 @@ extern "C" int vl_ln_bwd(const float* dy32, const float* z32, const float* mean,
   a.seed = seed;
   a.orig_stride = orig_row_stride; a.resid_stride = 1;
   hipStream_t s = (hipStream_t)stream;
-  switch (H / 256) {
+  switch ((H + 255) / 256) {
     case 1: return launch_bwd<1>(a, s, dgamma, dbeta, dbias);
     case 2: return launch_bwd<2>(a, s, dgamma, dbeta, dbias);
     case 3: return launch_bwd<3>(a, s, dgamma, dbeta, dbias);

@@ -57,7 +57,7 @@ int check_header(const char* fn, const int64_t* d) {
   VL_CHECK_ARG(d[VL_ST_MAGIC] == VL_ST_MAGIC_VALUE, "%s: descriptor magic mismatch (built for another library version?)", fn);
   VL_CHECK_ARG(d[VL_ST_B] > 0 && d[VL_ST_S] > 0 && d[VL_ST_H] > 0 && d[VL_ST_I] > 0 && d[VL_ST_NH] > 0 && d[VL_ST_NLAYERS] > 0,
                "%s: bad dimensions in the descriptor", fn);
-  VL_CHECK_ARG(d[VL_ST_H] == d[VL_ST_NH] * 64, "%s: head dim must be 64", fn);
+  VL_CHECK_ARG(d[VL_ST_H] == d[VL_ST_NH] * 64 || d[VL_ST_H] == d[VL_ST_NH] * 32, "%s: head dim must be 64 or 32", fn);
   return 0;
 }
 
@@ -89,7 +89,7 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
                 M, 3 * H, H, 3, VL_EPI_SPLIT, ptr<const float>(y[VL_LY_BQKV]), nullptr, nullptr, 0,
                 ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), nullptr, 3 * H, stream));
     VL_TRY(vl_attn2_fwd(ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), addmask, ptr<void>(y[VL_LY_CTX_HI]),
-                        ptr<void>(y[VL_LY_CTX_LO]), ptr<float>(y[VL_LY_LSE]), B, S, nh, 64, nq, p_att, seed_of(d[VL_ST_SEED0], s3), stream));
+                        ptr<void>(y[VL_LY_CTX_LO]), ptr<float>(y[VL_LY_LSE]), B, S, nh, H / nh, nq, p_att, seed_of(d[VL_ST_SEED0], s3), stream));
     VL_TRY(gemm(prof, ptr<void>(y[VL_LY_CTX_HI]), ptr<void>(y[VL_LY_CTX_LO]), H, ptr<void>(y[VL_LY_WO_HI]), ptr<void>(y[VL_LY_WO_LO]), H,
                 R, H, H, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_BO]), nullptr, ptr<float>(y[VL_LY_Z1]), H, nullptr, nullptr,
                 nullptr, 0, stream));
@@ -170,7 +170,7 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
     VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT1]), nullptr, H, ptr<void>(y[VL_LY_WO_T]), nullptr, H, R, H, H, 1, VL_EPI_BF16, nullptr,
                 nullptr, nullptr, 0, ptr<void>(y[VL_LY_DCTX16]), nullptr, nullptr, H, sm));
     VL_TRY(vl_attn2_bwd(ptr<void>(y[VL_LY_QKV_HI]), addmask, ptr<void>(y[VL_LY_DCTX16]), ptr<const float>(y[VL_LY_LSE]),
-                        ptr<void>(y[VL_LY_DQKV]), B, S, nh, 64, nq, p_att, seed_of(d[VL_ST_SEED0], s3), sm));
+                        ptr<void>(y[VL_LY_DQKV]), B, S, nh, H / nh, nq, p_att, seed_of(d[VL_ST_SEED0], s3), sm));
     if (ss != sm) {  // everything the side stream reads of this layer has been enqueued on the main stream
       hipError_t e = hipEventRecord(fork, sm);
       if (e == hipSuccess) e = hipStreamWaitEvent(ss, fork, 0);

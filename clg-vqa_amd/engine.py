@@ -427,10 +427,10 @@ class EngineBase(object):
     """Weight preparation (one launch per step), dropout seeds, dirty tracking shared by the UC2 and M3P engines."""
 
     def _init_common(self, H, nh):
-        if H % nh != 0 or H // nh != 64:
-            raise ValueError("clg_vqa_amd: the native attention kernel needs head dim 64 (hidden %d / heads %d)" % (H, nh))
-        if H % 256 != 0:
-            raise ValueError("clg_vqa_amd: hidden size must be a multiple of 256 for the native LayerNorm")
+        if H % nh != 0 or H // nh not in (32, 64):
+            raise ValueError("clg_vqa_amd: the native attention kernel needs head dim 64 or 32 (hidden %d / heads %d)" % (H, nh))
+        if H != 128 and H % 256 != 0:
+            raise ValueError("clg_vqa_amd: hidden size must be 128 or a multiple of 256 for the native LayerNorm")
         self._prepared = None
         self._dirty = True
         # optional: a zero-initialised, optimizer-owned fp32 buffer the word-embedding gradient is scatter-added

@@ -593,6 +593,63 @@ def test_attention2_forward_backward(B, T, V):
     assert rel <= 2e-2 and err <= 3e-2 * g.abs().max().item()  # P / dS are rounded to bf16 inside (2^-9 relative each)
 
 
+@pytest.mark.parametrize("B,S", [(3, 56), (2, 120), (1, 10)])
+def test_attention2_head_dim_32(B, S):
+    """head dim 32 (the tiny c1 config: hidden 128, 4 heads)."""
+    nh, dh = 4, 32
+    H = nh * dh
+    qkv = _rand(B * S, 3 * H, seed=44, scale=1.5)
+    hi, lo = _split(qkv)
+    addmask = torch.zeros(B * S, device=DEV)
+    addmask[S - 2:S] = -10000.0
+    ctx_hi = torch.full((B * S, H), float("nan"), dtype=BF16, device=DEV)
+    ctx_lo = torch.full_like(ctx_hi, float("nan"))
+    lse = torch.empty(B * nh * S, device=DEV)
+    ops.attn2_fwd(hi, lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, 0.0, 1)
+
+    def ref_fn(x):
+        x = x.view(B, S, 3, nh, dh)
+        q, k, v = x[:, :, 0].permute(0, 2, 1, 3), x[:, :, 1].permute(0, 2, 1, 3), x[:, :, 2].permute(0, 2, 1, 3)
+        sc = q @ k.transpose(-1, -2) / math.sqrt(dh) + addmask.double().view(B, 1, 1, S)
+        return (torch.softmax(sc, -1) @ v).permute(0, 2, 1, 3).reshape(B * S, H)
+
+    ref = ref_fn(hi.double() + lo.double())
+    got = ctx_hi.double() + ctx_lo.double()
+    assert (got - ref).abs().max().item() < 3e-5 * max(1.0, ref.abs().max().item())
+    d16 = _rand(B * S, H, seed=45).to(BF16)
+    qh = hi.double().clone().requires_grad_(True)
+    ref_fn(qh).backward(d16.double())
+    dqkv = torch.full((B * S, 3 * H), float("nan"), dtype=BF16, device=DEV)
+    ops.attn2_bwd(hi, addmask, d16, lse, dqkv, B, S, nh, dh, 0.0, 1)
+    rel = (dqkv.double() - qh.grad).norm().item() / qh.grad.norm().item()
+    assert rel <= 2e-2, rel
+
+
+@pytest.mark.parametrize("H", [128])
+def test_layernorm_hidden_128(H):
+    M = 37
+    y, resid = _rand(M, H, seed=5), _rand(M, H, seed=6)
+    gamma, beta = _rand(H, seed=7) + 1.0, _rand(H, seed=8)
+    out, mean, rstd = torch.empty(M, H, device=DEV), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    oh, ol = torch.empty(M, H, dtype=BF16, device=DEV), torch.empty(M, H, dtype=BF16, device=DEV)
+    z = y.clone()
+    ops.ln_fwd(z, resid, None, gamma, beta, 1e-5, out, oh, ol, mean, rstd, M, H)
+    zr = (y + resid).double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(zr, (H,), gd, bd, 1e-5)
+    torch.testing.assert_close(out.double(), ref.detach(), rtol=1e-5, atol=1e-5)
+    assert (oh.double() + ol.double() - ref.detach()).abs().max().item() < 1e-4
+    dy = _rand(M, H, seed=9)
+    ref.backward(dy.double())
+    dz, dg, db, dbias = torch.empty(M, H, device=DEV), torch.empty(H, device=DEV), torch.empty(H, device=DEV), torch.empty(H, device=DEV)
+    d16 = torch.empty(M, H, dtype=BF16, device=DEV)
+    ops.ln_bwd(dy, z, mean, rstd, gamma, dz, d16, None, dg, db, dbias, ops.ln_bwd_ws(M, H, DEV), M, H)
+    torch.testing.assert_close(dz.double(), zr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dg.double(), gd.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.double(), bd.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dbias.double(), zr.grad.sum(0), rtol=1e-4, atol=1e-4)
+
+
 def test_attention2_pooled_row_mode_equals_the_dense_run():
     """nq = 1 (only query 0 of every sample is live): ctx row 0 bit-equal to the dense run; the gradient equals the
     dense run fed with dO = 0 everywhere but row 0."""

@@ -84,6 +84,28 @@ def test_wide_layer_matches_reference_fixture():
     print("wide fixture: worst gradient rel-L2 error %.3e at %s" % worst)
 
 
+def test_tiny_c1_config_matches_reference_fixture():
+    """BASELINE config c1 (2 layers, hidden 128, 4 heads = head dim 32, I 512, bs 4) -- the reference's own
+    CPU-runnable plumbing case -- on the HIP path, against the fixture produced by the real reference."""
+    g = load_golden("uc2_tiny.npz")
+    config = golden_config(g)
+    assert config.hidden_size == 128 and config.num_attention_heads == 4
+    model, oracle = _build(config, int(g["seed"]))
+    batch = golden_batch(g)
+    loss, score, logits = _run_native(model, batch)
+    err = np.abs(logits.cpu().numpy() - g["logits"]).max()
+    print("tiny c1 fixture: max |logit err| = %.3e, loss %.4f vs %.4f, score %.2f" % (err, float(loss), float(g["loss"]), float(score)))
+    assert err <= LOGIT_TOL
+    assert abs(float(loss) - float(g["loss"])) <= 2e-4 * abs(float(g["loss"]))
+    assert float(score) == float(g["score"]) == 0.5
+    oracle.eval()
+    oracle.zero_grad()
+    oloss, _, _ = O.forward_train(oracle, batch)
+    oloss.backward()
+    worst = _compare_grads(model, {n: p.grad for n, p in oracle.named_parameters()})
+    print("tiny c1 fixture: worst gradient rel-L2 error %.3e at %s" % worst)
+
+
 def test_full_depth_matches_reference_fixture():
     """The full-depth trunk -- 12 layers, H 768, 12 heads, I 3072 (48 GEMMs deep), bs 8, vocab 2000 -- against the
     fixture produced by the REAL reference: logits within 1e-3, loss, score (non-zero in the fixture), every
