@@ -107,15 +107,24 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
                      ptr<const float>(y[VL_LY_LN2_G]), ptr<const float>(y[VL_LY_LN2_B]), eps, ptr<float>(y[VL_LY_OUT32]),
                      ptr<void>(y[VL_LY_OUT_HI]), ptr<void>(y[VL_LY_OUT_LO]), ptr<float>(y[VL_LY_MEAN2]), ptr<float>(y[VL_LY_RSTD2]),
                      R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 2), os, 1, stream));
-    if (y[VL_LY_T_X]) {
-      // training: the K-major images of this layer's X operands for the weight-gradient GEMMs of backward, written now,
-      // behind the layer, on the side stream -- the forward is MFMA-bound, its HBM bandwidth is idle
-      if (ss != (hipStream_t)stream) {
-        VL_CHECK_ARG(fork, "vl_stack_fwd: a side stream needs the fork event of the descriptor");
-        hipError_t e = hipEventRecord(fork, (hipStream_t)stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ss, fork, 0);
-        if (e != hipSuccess) return vl_set_error(-3, "vl_stack_fwd: stream fork: %s", hipGetErrorString(e));
-      }
+  }
+  // training: the K-major images of every layer's X operands {layer input, attention context, LayerNorm-1 output, GELU
+  // output} for the weight-gradient GEMMs of backward.  They are written on the side stream once the LAST layer of the
+  // stack has been enqueued: the head / loss / head-backward phase that follows is ~50 tiny latency-bound kernels
+  // (~0.6 ms during which the chip is idle), so this HBM-bound re-layout runs there instead of beside the GEMMs (written
+  // layer by layer beside the forward GEMMs it cost the QKV projection +40 %; written in backward it is 1.3 ms more work on
+  // the stream that already limits the backward GEMMs)
+  if (layer_end == L && d[VL_ST_FIELDS + VL_LY_T_X]) {
+    if (ss != (hipStream_t)stream) {
+      VL_CHECK_ARG(fork, "vl_stack_fwd: a side stream needs the fork event of the descriptor");
+      hipError_t e = hipEventRecord(fork, (hipStream_t)stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(ss, fork, 0);
+      if (e != hipSuccess) return vl_set_error(-3, "vl_stack_fwd: stream fork: %s", hipGetErrorString(e));
+    }
+    for (int64_t l = L - 1; l >= 0; --l) {  // the order backward consumes them in
+      const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
+      const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;
+      const int64_t R = pooled ? B : M;
       const int64_t tr[4 * VL_TR_FIELDS] = {
           y[VL_LY_X_HI], H, H, y[VL_LY_T_X], 0, 0,
           y[VL_LY_CTX_HI], H, H, y[VL_LY_T_CTX], 0, 0,
