@@ -49,7 +49,7 @@ class GemmTimer(object):
     def __init__(self, stack, capacity=512):
         from clg_vqa_amd._lib import header_constants
         c = header_constants()
-        self.HDR, self.PAIR = c["VL_PROF_HEADER"], c["VL_PROF_PAIR"]
+        self.HDR, self.PAIR, self.TAG_QKV_ATTN = c["VL_PROF_HEADER"], c["VL_PROF_PAIR"], c["VL_PROF_TAG_QKV_ATTN"]
         self.stack, self.capacity = stack, capacity
         self.events = []
         self.block = np.zeros(self.HDR + self.PAIR * capacity, dtype=np.int64)
@@ -74,7 +74,7 @@ class GemmTimer(object):
         for i in range(used):
             tag, flops = int(self.block[self.HDR + self.PAIR * i + 2]), float(self.block[self.HDR + self.PAIR * i + 3])
             ms = self.events[i][0].elapsed_time(self.events[i][1])
-            r = out.setdefault(tag // 16, dict(launches=0, flops=0.0, ms=0.0))
+            r = out.setdefault("qkv_attn" if tag == self.TAG_QKV_ATTN else tag // 16, dict(launches=0, flops=0.0, ms=0.0))
             r["launches"] += 1
             r["flops"] += flops
             r["ms"] += ms
@@ -370,6 +370,18 @@ def main():
                         mfma_busy_pmc=busy, pmc_source=src, launches=gs[3]["launches"],
                         avg_launch_us=round(1e3 * gs[3]["ms"] / gs[3]["launches"], 2),
                         algorithmic_flop_per_launch=round(gs[3]["flops"] / gs[3]["launches"]))
+            if "qkv_attn" in gs:
+                # the op north_star names (QKV projection + softmax(QK^T)V), forward, against its 70 % MFMA target: the
+                # projection runs 3 MFMA passes per algorithmic MAC for the 1e-3 logit contract, so the algorithmic
+                # ceiling of the op is 1/3 of the peak
+                q = gs["qkv_attn"]
+                aq = q["flops"] / (q["ms"] * 1e-3) / 1e12
+                roof["fused_attention"] = dict(
+                    op="vl_qkv_attention_fwd (QKV projection 3-pass bf16 + attention core, 2 launches sharing split-bf16 Q|K|V)",
+                    achieved=round(aq, 2), frac=round(aq / MFMA_BF16_PEAK_TFLOPS, 4), target_frac=0.70,
+                    ceiling_frac_3pass=round(1.0 / 3.0, 4), mfma_issue_frac=round(3 * aq / MFMA_BF16_PEAK_TFLOPS, 4),
+                    launches=q["launches"], avg_us=round(1e3 * q["ms"] / q["launches"], 2),
+                    algorithmic_gflop_per_launch=round(q["flops"] / q["launches"] / 1e9, 2))
             if 1 in gs:
                 a1 = gs[1]["flops"] / (gs[1]["ms"] * 1e-3) / 1e12
                 roof["backward_gemm"] = dict(kernel="gemm3_kernel<1,*> (backward dX GEMMs, bf16 MFMA, 8-wave ping-pong)", achieved=round(a1, 2),

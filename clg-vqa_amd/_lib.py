@@ -38,6 +38,10 @@ _SIGS = {
     "vl_colsum_finalize": (c_int, [P, c_int64, c_int64, P, c_int64, c_int, P]),
     "vl_dw_grouped": (c_int, [P, c_int64, c_int64, c_int, P]),
     "vl_colreduce_multi": (c_int, [P, c_int64, c_int, P]),
+    "vl_qkv_attention_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float,
+                                     c_uint64, P]),
+    "vl_qkv_attention_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64,
+                                     P]),
     "vl_attn2_fwd": (c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_attn2_bwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_ln_fwd": (c_int, [P, P, P, c_int64, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64,

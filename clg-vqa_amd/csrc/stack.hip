@@ -32,23 +32,30 @@ inline uint64_t seed_of(int64_t seed0, int site) { return ((uint64_t)seed0 * 409
 
 #define VL_TRY(call) do { if (int rc_ = (call)) return rc_; } while (0)
 
+// caller-owned event pairs (descriptor field VL_ST_PROF): every stride-th timed launch is bracketed
+int64_t* prof_begin(int64_t* prof, void* stream) {
+  if (!prof) return nullptr;
+  const int64_t n = prof[2]++;
+  if (!(prof[0] > 0 && n % prof[0] == 0 && prof[3] < prof[1])) return nullptr;
+  int64_t* pair = prof + VL_PROF_HEADER + VL_PROF_PAIR * prof[3]++;
+  (void)hipEventRecord(reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(pair[0])), (hipStream_t)stream);
+  return pair;
+}
+void prof_end(int64_t* pair, int64_t tag, int64_t flops, void* stream) {
+  if (!pair) return;
+  (void)hipEventRecord(reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(pair[1])), (hipStream_t)stream);
+  pair[2] = tag;
+  pair[3] = flops;
+}
+
 // vl_gemm_nt, optionally bracketed by a caller-owned event pair (descriptor field VL_ST_PROF)
 int gemm(int64_t* prof, const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
          int64_t M, int64_t N, int64_t K, int passes, int epi, const float* bias, const float* resid, float* out32,
          int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream) {
-  int64_t* pair = nullptr;
-  if (prof) {
-    const int64_t n = prof[2]++;
-    if (prof[0] > 0 && n % prof[0] == 0 && prof[3] < prof[1]) pair = prof + VL_PROF_HEADER + VL_PROF_PAIR * prof[3]++;
-  }
-  if (pair) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(pair[0])), (hipStream_t)stream);
+  int64_t* pair = prof_begin(prof, stream);
   const int rc = vl_gemm_nt(a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, passes, epi, bias, resid, out32, ldc, out_hi, out_lo,
                             aux16, ld16, stream);
-  if (pair) {
-    (void)hipEventRecord(reinterpret_cast<hipEvent_t>(static_cast<uintptr_t>(pair[1])), (hipStream_t)stream);
-    pair[2] = passes * 16 + epi;
-    pair[3] = 2 * M * N * K;
-  }
+  prof_end(pair, passes * 16 + epi, 2 * M * N * K, stream);
   return rc;
 }
 
@@ -62,6 +69,34 @@ int check_header(const char* fn, const int64_t* d) {
 }
 
 }  // namespace
+
+// The op north_star names -- QKV projection + softmax(QK^T)V over the mixed (token, box) sequence -- as one entry point.
+// Two launches share the split-bf16 Q|K|V (no fp32 copy of the projection goes through HBM): the 3-pass projection GEMM
+// with the (hi, lo) epilogue, then the attention kernel.  A single-kernel fusion was analysed and not built: the
+// projection must land in HBM anyway (backward reads it), so fusion only saves the attention kernel's re-read of it
+// (132 MB per layer, largely Infinity-Cache hits right after the write, ~10-20 us), while a 224 x 192 per-(4 samples,
+// head) GEMM tile re-reads X twelve times through L2 and has 20 % fewer FLOP per LDS byte than the 256 x 256 tile
+// ("Fused V&L attention").
+extern "C" int vl_qkv_attention_fwd(const void* x_hi, const void* x_lo, const void* wqkv_hi, const void* wqkv_lo,
+                                    const float* bqkv, const float* addmask, void* qkv_hi, void* qkv_lo, void* ctx_hi,
+                                    void* ctx_lo, float* lse, int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq,
+                                    float p_drop, uint64_t seed, void* stream) {
+  const int64_t H = nh * dh, M = B * S;
+  VL_TRY(vl_gemm_nt(x_hi, x_lo, H, wqkv_hi, wqkv_lo, H, M, 3 * H, H, 3, VL_EPI_SPLIT, bqkv, nullptr, nullptr, 0, qkv_hi, qkv_lo,
+                    nullptr, 3 * H, stream));
+  return vl_attn2_fwd(qkv_hi, qkv_lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, nq, p_drop, seed, stream);
+}
+
+// Backward of the same op w.r.t. its input: dctx16 -> dqkv16 (attention backward) -> dx32 = dqkv . W_qkv (+ resid32).
+// (The weight / bias gradients of the projection are products over the batch rows: vl_transpose_blocked + vl_dw_grouped.)
+extern "C" int vl_qkv_attention_bwd(const void* qkv_hi, const float* addmask, const void* dctx16, const float* lse,
+                                    const void* wqkv_t, const float* resid32, void* dqkv16, float* dx32, int64_t B,
+                                    int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop, uint64_t seed, void* stream) {
+  const int64_t H = nh * dh, M = B * S;
+  VL_TRY(vl_attn2_bwd(qkv_hi, addmask, dctx16, lse, dqkv16, B, S, nh, dh, nq, p_drop, seed, stream));
+  return vl_gemm_nt(dqkv16, nullptr, 3 * H, wqkv_t, nullptr, 3 * H, M, H, 3 * H, 1, VL_EPI_F32, nullptr, resid32, dx32, H, nullptr,
+                    nullptr, nullptr, 0, stream);
+}
 
 extern "C" int64_t vl_stack_desc_len(int64_t n_layers) { return VL_ST_FIELDS + n_layers * VL_LY_FIELDS; }
 
@@ -84,12 +119,16 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
     // B live rows (R), in compact [B, .] buffers, with the dropout counters / row masks of the original rows (stride S)
     const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;
     const int64_t R = pooled ? B : M, nq = pooled ? 1 : S, os = pooled ? S : 1;
-    // Q | K | V = X W^T + b, written as the (hi, lo) split the attention kernel reads
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_X_HI]), ptr<void>(y[VL_LY_X_LO]), H, ptr<void>(y[VL_LY_WQKV_HI]), ptr<void>(y[VL_LY_WQKV_LO]), H,
-                M, 3 * H, H, 3, VL_EPI_SPLIT, ptr<const float>(y[VL_LY_BQKV]), nullptr, nullptr, 0,
-                ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), nullptr, 3 * H, stream));
-    VL_TRY(vl_attn2_fwd(ptr<void>(y[VL_LY_QKV_HI]), ptr<void>(y[VL_LY_QKV_LO]), addmask, ptr<void>(y[VL_LY_CTX_HI]),
-                        ptr<void>(y[VL_LY_CTX_LO]), ptr<float>(y[VL_LY_LSE]), B, S, nh, H / nh, nq, p_att, seed_of(d[VL_ST_SEED0], s3), stream));
+    // Q | K | V = X W^T + b as the (hi, lo) split, then attention: the fused V&L attention op (timed as ONE op, tag
+    // VL_PROF_TAG_QKV_ATTN: projection + core FLOPs against the interval around both launches)
+    {
+      int64_t* pair = prof_begin(prof, stream);
+      VL_TRY(vl_qkv_attention_fwd(ptr<void>(y[VL_LY_X_HI]), ptr<void>(y[VL_LY_X_LO]), ptr<void>(y[VL_LY_WQKV_HI]),
+                                  ptr<void>(y[VL_LY_WQKV_LO]), ptr<const float>(y[VL_LY_BQKV]), addmask, ptr<void>(y[VL_LY_QKV_HI]),
+                                  ptr<void>(y[VL_LY_QKV_LO]), ptr<void>(y[VL_LY_CTX_HI]), ptr<void>(y[VL_LY_CTX_LO]),
+                                  ptr<float>(y[VL_LY_LSE]), B, S, nh, H / nh, nq, p_att, seed_of(d[VL_ST_SEED0], s3), stream));
+      prof_end(pair, VL_PROF_TAG_QKV_ATTN, 2 * M * 3 * H * H + 4 * B * nq * S * H, stream);
+    }
     VL_TRY(gemm(prof, ptr<void>(y[VL_LY_CTX_HI]), ptr<void>(y[VL_LY_CTX_LO]), H, ptr<void>(y[VL_LY_WO_HI]), ptr<void>(y[VL_LY_WO_LO]), H,
                 R, H, H, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_BO]), nullptr, ptr<float>(y[VL_LY_Z1]), H, nullptr, nullptr,
                 nullptr, 0, stream));

@@ -144,6 +144,19 @@ int vl_attn2_fwd(const void* qkv_hi, const void* qkv_lo, const float* addmask, v
 int vl_attn2_bwd(const void* qkv_hi, const float* addmask, const void* dctx16, const float* lse, void* dqkv16,
                  int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop, uint64_t seed, void* stream);
 
+/* The op north_star names -- QKV projection + masked softmax(QK^T)V over the [text ; box] sequence (encoders.py:229-341) --
+ * as one entry point per direction (SURVEY 8b vl_qkv_attention_{fwd,bwd}).  Forward = the 3-pass projection GEMM with the
+ * (hi, lo) epilogue + vl_attn2_fwd, two launches sharing the split-bf16 Q|K|V (x (hi, lo) [B*S, H], wqkv (hi, lo) [3H, H],
+ * bqkv [3H]; qkv_hi / qkv_lo [B*S, 3H] are outputs, kept for backward).  Backward w.r.t. the input = vl_attn2_bwd + the dX
+ * GEMM dx32 = dqkv16 . wqkv_t (+ resid32; wqkv_t = transposed hi weights [H, 3H]).  Why two launches and not one kernel:
+ * DESIGN.md "Fused V&L attention". */
+int vl_qkv_attention_fwd(const void* x_hi, const void* x_lo, const void* wqkv_hi, const void* wqkv_lo, const float* bqkv,
+                         const float* addmask, void* qkv_hi, void* qkv_lo, void* ctx_hi, void* ctx_lo, float* lse,
+                         int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop, uint64_t seed, void* stream);
+int vl_qkv_attention_bwd(const void* qkv_hi, const float* addmask, const void* dctx16, const float* lse, const void* wqkv_t,
+                         const float* resid32, void* dqkv16, float* dx32, int64_t B, int64_t S, int64_t nh, int64_t dh,
+                         int64_t nq, float p_drop, uint64_t seed, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------
  * (dropout +) residual + LayerNorm, forward and backward.
  * Replaces apex fused_layer_norm_cuda.forward_affine / backward_affine (apex/csrc/layer_norm_cuda.cpp:139-239,
@@ -320,9 +333,11 @@ enum {
  * points to a HOST int64 block owned by the caller: [0] stride (every stride-th GEMM launch is bracketed), [1] capacity
  * (event pairs), [2] launch counter, [3] pairs used, then per pair 4 values {event0, event1 (hipEvent_t handles created
  * by the caller with timing enabled), tag, flops}: the library records the events around the launch and fills tag
- * (= passes * 16 + epilogue) and flops (2 M N K); the caller reads the elapsed times. */
+ * (= passes * 16 + epilogue for a GEMM; VL_PROF_TAG_QKV_ATTN for the fused attention op) and the algorithmic flops; the
+ * caller reads the elapsed times. */
 #define VL_PROF_HEADER 4
 #define VL_PROF_PAIR 4
+#define VL_PROF_TAG_QKV_ATTN 1000 /* the fused V&L attention op (projection + core), forward */
 int64_t vl_stack_desc_len(int64_t n_layers);
 int vl_stack_fwd(const int64_t* desc, int64_t layer_begin, int64_t layer_end, void* stream_main, void* stream_side);
 int vl_stack_bwd(const int64_t* desc, int64_t layer_hi, int64_t layer_lo, void* stream_main, void* stream_side);

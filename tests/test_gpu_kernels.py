@@ -840,3 +840,43 @@ def test_gqa_loss_kernel_matches_the_reference_arithmetic(B, C):
     assert abs(out[0].item() - ref.item()) <= 2e-6 * abs(ref.item()), (out[0].item(), ref.item())
     assert out[1].item() == ref_score.item()
     torch.testing.assert_close(dl.double(), z.grad, rtol=2e-5, atol=2e-5 * z.grad.abs().max().item())
+
+
+def test_qkv_attention_entry_points_equal_the_two_step_sequence():
+    """vl_qkv_attention_fwd / _bwd == projection GEMM (split epilogue) + attention, and attention backward +
+    dX GEMM, bit for bit; and fp32-grade against fp64 math."""
+    from clg_vqa_amd import _lib
+    B, S, nh, dh = 2, 56, 12, 64
+    H, M = nh * dh, B * S
+    x, w = _rand(M, H, seed=101), _rand(3 * H, H, seed=102, scale=0.05)
+    bias = _rand(3 * H, seed=103, scale=0.1)
+    xh, xl = _split(x)
+    wh, wl = _split(w)
+    addmask = torch.zeros(M, device=DEV)
+    addmask[S - 3:S] = -10000.0
+    L = _lib.lib()
+    mk = lambda *s: torch.empty(*s, dtype=BF16, device=DEV)  # noqa: E731
+    q_hi, q_lo, c_hi, c_lo, lse = mk(M, 3 * H), mk(M, 3 * H), mk(M, H), mk(M, H), torch.empty(B * nh * S, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(L.vl_qkv_attention_fwd(xh.data_ptr(), xl.data_ptr(), wh.data_ptr(), wl.data_ptr(), bias.data_ptr(),
+                                      addmask.data_ptr(), q_hi.data_ptr(), q_lo.data_ptr(), c_hi.data_ptr(), c_lo.data_ptr(),
+                                      lse.data_ptr(), B, S, nh, dh, S, 0.0, 1, st), "vl_qkv_attention_fwd")
+    r_hi, r_lo, rc_hi, rc_lo, rlse = mk(M, 3 * H), mk(M, 3 * H), mk(M, H), mk(M, H), torch.empty_like(lse)
+    ops.gemm_nt(xh, xl, wh, wl, M, 3 * H, H, 3, EPI_SPLIT, bias=bias, out_hi=r_hi, out_lo=r_lo)
+    ops.attn2_fwd(r_hi, r_lo, addmask, rc_hi, rc_lo, rlse, B, S, nh, dh, 0.0, 1)
+    assert torch.equal(q_hi, r_hi) and torch.equal(c_hi, rc_hi) and torch.equal(c_lo, rc_lo) and torch.equal(lse, rlse)
+    qkv = x.double() @ w.double().t() + bias.double()
+    ref, _ = _attn_ref(qkv, addmask.double().view(B, S), B, S, nh)
+    assert ((c_hi.double() + c_lo.double()) - ref).abs().max().item() < 5e-5 * max(1.0, ref.abs().max().item())
+    # backward: dctx -> dqkv -> dx = dqkv W + resid
+    d16 = _rand(M, H, seed=104).to(BF16)
+    wt = wh.t().contiguous()  # [H, 3H]
+    resid = _rand(M, H, seed=105)
+    dqkv, dx = mk(M, 3 * H), torch.empty(M, H, device=DEV)
+    _lib.check(L.vl_qkv_attention_bwd(q_hi.data_ptr(), addmask.data_ptr(), d16.data_ptr(), lse.data_ptr(), wt.data_ptr(),
+                                      resid.data_ptr(), dqkv.data_ptr(), dx.data_ptr(), B, S, nh, dh, S, 0.0, 1, st),
+               "vl_qkv_attention_bwd")
+    rdq, rdx = mk(M, 3 * H), torch.empty(M, H, device=DEV)
+    ops.attn2_bwd(q_hi, addmask, d16, lse, rdq, B, S, nh, dh, 0.0, 1)
+    ops.gemm_nt(rdq, None, wt, None, M, H, 3 * H, 1, EPI_F32, resid=resid, out32=rdx)
+    assert torch.equal(dqkv, rdq) and torch.equal(dx, rdx)
