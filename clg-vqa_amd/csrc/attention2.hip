@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
         sc[t] = mfma(kl, qh[ks], sc[t]);
         sc[t] = mfma(kh, qh[ks], sc[t]);
       }
+      asm volatile("" ::: "memory");  // keep the next tile's LDS reads here: hoisting all NT tiles' fragments costs ~100 VGPRs
     }
     // softmax over the keys of query q: this lane holds keys 16 t + 4 g + r
     float m = -INFINITY;
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
         o[dt] = mfma(vl, ph, o[dt]);
         o[dt] = mfma(vh, ph, o[dt]);
       }
+      asm volatile("" ::: "memory");
     }
     if (q < p.nq) {
       const long orow = (long)b * p.ctx_rows + q;
@@ -320,6 +322,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
         pv[t][r] = pr;
         kd[t][r] = x;
       }
+      asm volatile("" ::: "memory");  // (see the forward kernel: keeps the LDS fragment reads of later tiles from being hoisted)
     }
     delta += __shfl_xor(delta, 16, 64);
     delta += __shfl_xor(delta, 32, 64);
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
       const int r1 = (16 * t1 + 4 * g + qq) * PITCH + 8 * pp;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) o[dt] = mfma(tr_frag2(sK + r0 + 32 * dt, sK + r1 + 32 * dt), dsb, o[dt]);
+      asm volatile("" ::: "memory");
     }
     if (q < S) {
 #pragma unroll

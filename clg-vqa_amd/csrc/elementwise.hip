@@ -303,8 +303,9 @@ __global__ void loc_fwd_kernel(const float* __restrict__ loc, const float* __res
 }
 __global__ __launch_bounds__(256) void loc_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ dy,
                                                       float* dw, float* db, long R, int L, int H) {
-  const long r0 = (long)blockIdx.x * 64;
-  const long r1 = r0 + 64 < R ? r0 + 64 : R;
+  // 16 rows per workgroup: 64 (144 workgroups at c2, one 64-deep dependent load chain per thread) left the chip idle
+  const long r0 = (long)blockIdx.x * 16;
+  const long r1 = r0 + 16 < R ? r0 + 16 : R;
   for (int c = threadIdx.x; c < H; c += 256) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float accb = 0.f;
@@ -588,7 +589,7 @@ extern "C" int vl_loc_linear_fwd(const float* loc, const float* w, const float* 
 extern "C" int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db, int64_t R, int64_t L,
                                  int64_t H, void* stream) {
   VL_CHECK_ARG(loc && dy32 && dw && db && R > 0 && L > 0 && L <= 8 && H > 0, "vl_loc_linear_bwd: bad arguments (L <= 8)");
-  hipLaunchKernelGGL(loc_bwd_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), 0, (hipStream_t)stream, loc, dy32, dw,
+  hipLaunchKernelGGL(loc_bwd_kernel, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, (hipStream_t)stream, loc, dy32, dw,
                      db, (long)R, (int)L, (int)H);
   VL_CHECK_LAUNCH("vl_loc_linear_bwd");
   return 0;
