@@ -16,23 +16,19 @@ P = c_void_p
 _SIGS = {
     "vl_version": (c_int, []),
     "vl_last_error": (c_char_p, []),
-    "vl_debug_set": (c_int, [c_int, c_int]),
     "vl_gemm_nt": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, P, P, P, c_int64,
                            P, P, P, c_int64, P]),
+    "vl_gemm_nt_ex": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, P, P, P, c_int64,
+                              P, P, P, c_int64, c_int, P]),
     "vl_gemm_splitk_plan": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_splitk_ws_floats": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_nt_splitk": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P]),
     "vl_gemm_tn_splitk": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P]),
-    "vl_gemm_tn_grouped": (c_int, [P, c_int64, c_int64, c_int64, P]),
-    "vl_gemm_tn_splitk_to": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, c_int64, c_int, P]),
-    "vl_ln_debug_blocks": (c_int, [c_int]),
     "vl_ln_bwd_reduce": (c_int, [P, c_int64, c_int64, P, P, P, P]),
     "vl_ln_bwd_reduce2": (c_int, [P, c_int64, P, P, P, P, c_int64, P, P, P, c_int64, c_int, P]),
     "vl_stack_desc_len": (c_int64, [c_int64]),
     "vl_stack_fwd": (c_int, [P, c_int64, c_int64, P, P]),
     "vl_stack_bwd": (c_int, [P, c_int64, c_int64, P, P]),
-    "vl_attn_fwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
-    "vl_attn_bwd": (c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_blocked_elems": (c_int64, [c_int64, c_int64]),
     "vl_transpose_blocked": (c_int, [P, c_int64, c_int64, c_int64, P]),
     "vl_colsum_finalize": (c_int, [P, c_int64, c_int64, P, c_int64, c_int, P]),

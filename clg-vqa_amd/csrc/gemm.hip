@@ -30,11 +30,9 @@
 
 namespace {
 
-int g_force_bn = 0;       // tuning knobs (vl_debug_set): 0 = automatic
-int g_force_generic = 0;
-int g_pingpong = 1;   // 8-wave ping-pong kernel (key 7): 0 = off, 1 = automatic tile width, 2 / 3 = force 256 / 192, 4 = cost model only
-int g_pp3 = 1;        // key 8: 3-pass products on the ping-pong kernel too
-int g_tile224 = 1;    // key 9: allow the 224 x 256 tile
+// Kernel / tile selection is a per-call argument (`tile` of vl_gemm_nt_ex; the library holds no mutable state):
+//   0 automatic | 2 / 3 / 5 ping-pong kernel with 256x256 / 256x192 / 224x256 tiles | 4 ping-pong, cost model only
+//   6 single-barrier kernel (automatic width) | 7 generic 128x128 kernel | 128 / 192 / 256 single-barrier kernel of that width
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -50,6 +48,7 @@ struct GemmArgs {
   int vec;                      // 1: leading dimensions / pointers allow the 16-byte (fp32) / 8-byte (bf16) epilogue
   int splits;                   // TN kernel: number of K-ranges (1-D grid over splits x tiles)
   int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
+  int tile;                     // host-side kernel / tile selection (see above); not read by the kernels
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -838,29 +837,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
-// Same sum, scattered: rows [t * seg_rows, (t+1) * seg_rows) of the [M, N] result go to outs[t] (each a contiguous
-// [seg_rows, N] buffer, e.g. the query / key / value weight gradients inside the optimizer's flat arena), optionally
-// added to what is there (gradient accumulation over micro-batches).
-struct ReduceDst { float* out[4]; };
-__global__ __launch_bounds__(256) void splitk_reduce_to_kernel(const float* __restrict__ ws, int splits, long n4,
-                                                               long seg_n4, ReduceDst dst, int accumulate) {
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    float4 acc = reinterpret_cast<const float4*>(ws)[i];
-    for (int s = 1; s < splits; ++s) {
-      const float4 v = reinterpret_cast<const float4*>(ws)[(long)s * n4 + i];
-      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-    }
-    const int t = (int)(i / seg_n4);
-    float4* o = reinterpret_cast<float4*>(dst.out[t]) + (i - (long)t * seg_n4);
-    if (accumulate) {
-      const float4 old = *o;
-      acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w;
-    }
-    *o = acc;
-  }
-}
-
 template <int NSPLIT, int EPI>
 int launch(const GemmArgs& a, hipStream_t stream, int splits = 1) {
   const size_t lds = (NSPLIT == 3 ? 4 : 2) * TILE_BYTES;
@@ -917,11 +893,11 @@ int launch2(const GemmArgs& a, hipStream_t stream, int splits) {
 
 
 // BN for the fast path: fewest "rounds x tile width" over the 256 CUs (one 512-thread workgroup per CU)
-inline int pick_bn(int64_t M, int64_t N, int splits) {
+inline int pick_bn(int64_t M, int64_t N, int splits, int tile) {
   const int64_t tm = (M + 255) / 256;
   int best = 256;
   int64_t best_cost = -1;
-  if (g_force_bn == 256 || g_force_bn == 192 || g_force_bn == 128) return g_force_bn;
+  if (tile == 256 || tile == 192 || tile == 128) return tile;
   const int cands[3] = {256, 192, 128};
   for (int c = 0; c < 3; ++c) {
     const int bn = cands[c];
@@ -932,14 +908,15 @@ inline int pick_bn(int64_t M, int64_t N, int splits) {
   return best;
 }
 
-inline bool fast_ok(int64_t M, int64_t K, int64_t k_len, int passes) {
+inline bool fast_ok(int64_t M, int64_t K, int64_t k_len, int passes, int tile) {
   const int ks = passes == 3 ? 32 : 64;
-  return !g_force_generic && M >= 256 && (K % ks) == 0 && (k_len % ks) == 0;
+  return tile != 7 && M >= 256 && (K % ks) == 0 && (k_len % ks) == 0;
 }
 
 template <int NSPLIT, int EPI>
 int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
-  if (splits == 1 && g_pingpong && (NSPLIT == 1 || g_pp3) && !g_force_generic && a.M >= 256 && a.N >= 192 && (a.K % (NSPLIT == 3 ? 32 : 64)) == 0) {
+  const int g_pingpong = (a.tile == 0) ? 1 : (a.tile == 2 || a.tile == 3 || a.tile == 4 || a.tile == 5) ? a.tile : 0;
+  if (splits == 1 && g_pingpong && a.M >= 256 && a.N >= 192 && (a.K % (NSPLIT == 3 ? 32 : 64)) == 0) {
     // tile shape by "rounds over the 256 CUs x tile area" (key 7: 1 = automatic, 2 / 3 / 5 = force 256x256 / 256x192 /
     // 224x256).  The 224-row tile exists for the two N = 3072 products (FFN1 forward, its dX backward): at
     // M = 14336 they are 672 tiles = 2.6 rounds of 256x256 but exactly 3 full rounds of 224x256.
@@ -950,12 +927,12 @@ int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
     const bool wide = g_pingpong == 2 || (g_pingpong != 3 && (c256 <= c192 || (NSPLIT == 1 && g_pingpong == 1 && a.N >= 256)));
     if constexpr ((NSPLIT == 3 && EPI == VL_EPI_GELU_SPLIT) || (NSPLIT == 1 && EPI == VL_EPI_DGELU_BF16)) {
       const int64_t c224 = (((a.M + 223) / 224) * ((a.N + 255) / 256) + 255) / 256 * 224;
-      if (g_pingpong == 5 || (g_pingpong == 1 && g_tile224 && wide && c224 < c256)) return launch3<NSPLIT, EPI, 2>(a, s);
+      if (g_pingpong == 5 || (g_pingpong == 1 && wide && c224 < c256)) return launch3<NSPLIT, EPI, 2>(a, s);
     }
     return wide ? launch3<NSPLIT, EPI, 0>(a, s) : launch3<NSPLIT, EPI, 1>(a, s);
   }
-  if (fast_ok(a.M, a.K, a.k_len, NSPLIT)) {
-    switch (pick_bn(a.M, a.N, splits)) {
+  if (fast_ok(a.M, a.K, a.k_len, NSPLIT, a.tile)) {
+    switch (pick_bn(a.M, a.N, splits, a.tile)) {
       case 256: return launch2<NSPLIT, EPI, 256>(a, s, splits);
       case 192: return launch2<NSPLIT, EPI, 192>(a, s, splits);
       default: return launch2<NSPLIT, EPI, 128>(a, s, splits);
@@ -984,7 +961,18 @@ extern "C" int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const
                           int64_t ldb, int64_t M, int64_t N, int64_t K, int passes, int epilogue,
                           const float* bias, const float* resid32, float* out32, int64_t ldc, void* out_hi,
                           void* out_lo, void* aux16, int64_t ld16, void* stream) {
+  return vl_gemm_nt_ex(a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, passes, epilogue, bias, resid32, out32, ldc, out_hi, out_lo,
+                       aux16, ld16, 0, stream);
+}
+
+// ... with an explicit kernel / tile selection (tests and micro-benchmarks; 0 = the automatic choice of vl_gemm_nt)
+extern "C" int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
+                             int64_t ldb, int64_t M, int64_t N, int64_t K, int passes, int epilogue,
+                             const float* bias, const float* resid32, float* out32, int64_t ldc, void* out_hi,
+                             void* out_lo, void* aux16, int64_t ld16, int tile, void* stream) {
   VL_CHECK_ARG(passes == 1 || passes == 3, "vl_gemm_nt: passes must be 1 or 3 (got %d)", passes);
+  VL_CHECK_ARG(tile == 0 || (tile >= 2 && tile <= 7) || tile == 128 || tile == 192 || tile == 256,
+               "vl_gemm_nt_ex: unknown tile selection %d", tile);
   VL_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
                "vl_gemm_nt: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
   VL_CHECK_ARG(a_hi && b_hi, "vl_gemm_nt: null operand");
@@ -1010,7 +998,7 @@ extern "C" int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const
   a.bias = bias; a.resid = resid32; a.out32 = out32; a.ldc = ldc;
   a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.aux16 = (bf16_raw*)aux16; a.ld16 = ld16;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
-  a.k_len = (int)K; a.slab_stride = 0;
+  a.k_len = (int)K; a.slab_stride = 0; a.tile = tile;
   a.vec8 = (ld16 & 7) == 0 && aligned16(bias) && aligned16(out_hi) && aligned16(out_lo) && aligned16(aux16);
   a.vec = ((ldc | ld16) & 3) == 0 && aligned16(bias) && aligned16(resid32) && aligned16(out32) &&
           ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo) |
@@ -1076,27 +1064,12 @@ extern "C" int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi
   return 0;
 }
 
-// A/B knobs for benchmarking (not part of the drop-in surface): 1 = BN of the single-barrier kernel (0 = auto),
-// 2 = force the generic 128x128 kernel, 7 = ping-pong kernel (0 off, 1 auto, 2 / 3 / 5 = force 256x256 / 256x192 /
-// 224x256 tiles, 4 = cost model only), 8 = ping-pong for 3-pass products, 9 = allow the 224x256 tile.
-extern "C" int vl_debug_set(int key, int value) {
-  if (key == 1) g_force_bn = value;
-  else if (key == 2) g_force_generic = value;
-  else if (key == 7) g_pingpong = value;
-  else if (key == 8) g_pp3 = value;
-  else if (key == 9) g_tile224 = value;
-  else return vl_set_error(-1, "vl_debug_set: unknown key %d", key);
-  return 0;
-}
-
 // dW[M,N] = A^T B with A [K, M] (lda), B [K, N] (ldb) row-major bf16 (the activations as they sit in HBM), K = the
 // B*S batch rows, split over `splits` workgroups per output tile (see vl_gemm_nt_splitk).  Needs K % 64 == 0,
 // M, N multiples of 8 and >= 16; otherwise returns -2 and the caller uses the transposing path.
 namespace {
 int tn_splitk_impl(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, int64_t K,
-                   int64_t splits, float* ws, float* out32, float* const* outs, int64_t nout, int accumulate,
-                   void* stream) {
-  const bool scatter = outs != nullptr;
+                   int64_t splits, float* ws, float* out32, void* stream) {
   GemmArgs g{};
   g.a_hi = (const bf16_raw*)a; g.b_hi = (const bf16_raw*)b;
   g.lda = lda; g.ldb = ldb; g.M = (int)M; g.N = (int)N; g.K = (int)K;
@@ -1105,7 +1078,7 @@ int tn_splitk_impl(const void* a, int64_t lda, const void* b, int64_t ldb, int64
   k_len = (k_len + 63) / 64 * 64;
   const int eff = (int)((K + k_len - 1) / k_len);
   g.k_len = (int)k_len;
-  const bool direct = eff == 1 && !scatter;  // a single K-range writes the result itself
+  const bool direct = eff == 1;  // a single K-range writes the result itself
   g.out32 = direct ? out32 : ws;
   g.slab_stride = direct ? 0 : M * N;
   const int bn = (N % 256 == 0 || N > 1024) ? 256 : 128;
@@ -1128,14 +1101,7 @@ int tn_splitk_impl(const void* a, int64_t lda, const void* b, int64_t ldb, int64
     const long n4 = (long)(M * N / 4);
     long gr = (n4 + 255) / 256;
     if (gr > 2048) gr = 2048;
-    if (scatter) {
-      ReduceDst d{};
-      for (int64_t t = 0; t < nout; ++t) d.out[t] = outs[t];
-      hipLaunchKernelGGL(splitk_reduce_to_kernel, dim3((unsigned)gr), dim3(256), 0, s, ws, eff, n4,
-                         (long)(M / nout * N / 4), d, accumulate);
-    } else {
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gr), dim3(256), 0, s, ws, eff, n4, out32);
-    }
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)gr), dim3(256), 0, s, ws, eff, n4, out32);
     VL_CHECK_LAUNCH("vl_gemm_tn_splitk(reduce)");
   }
   return 0;
@@ -1153,21 +1119,5 @@ extern "C" int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int6
                "vl_gemm_tn_splitk: bad arguments");
   if (!tn_shape_ok(a, lda, b, ldb, M, N, K, ws) || !aligned16(out32))
     return vl_set_error(-2, "vl_gemm_tn_splitk: shape not supported by the TN fast path");
-  return tn_splitk_impl(a, lda, b, ldb, M, N, K, splits, ws, out32, nullptr, 0, 0, stream);
-}
-
-// Same product with the rows of the result scattered over `nout` (1..4) destination buffers: rows
-// [t * M / nout, (t+1) * M / nout) go to outs[t] ([M / nout, N] contiguous fp32 each; `outs` is a HOST array), added to
-// their contents when accumulate != 0.  The engine points these at the optimizer's flat gradient arena (the packed
-// Q/K/V gradient lands in three separate parameters), so no gradient copy is needed.  ws: splits * M * N floats, always.
-extern "C" int vl_gemm_tn_splitk_to(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N,
-                                    int64_t K, int64_t splits, float* ws, float* const* outs, int64_t nout,
-                                    int accumulate, void* stream) {
-  VL_CHECK_ARG(a && b && outs && ws && M > 0 && N > 0 && K > 0 && splits >= 1 && splits <= 64 && nout >= 1 && nout <= 4 &&
-               M % nout == 0 && (M / nout * N) % 4 == 0, "vl_gemm_tn_splitk_to: bad arguments");
-  for (int64_t t = 0; t < nout; ++t)
-    VL_CHECK_ARG(outs[t] && aligned16(outs[t]), "vl_gemm_tn_splitk_to: destination %lld must be non-null and 16-byte aligned", (long long)t);
-  if (!tn_shape_ok(a, lda, b, ldb, M, N, K, ws))
-    return vl_set_error(-2, "vl_gemm_tn_splitk_to: shape not supported by the TN fast path");
-  return tn_splitk_impl(a, lda, b, ldb, M, N, K, splits, ws, nullptr, outs, nout, accumulate, stream);
+  return tn_splitk_impl(a, lda, b, ldb, M, N, K, splits, ws, out32, stream);
 }

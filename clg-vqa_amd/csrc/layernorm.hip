@@ -252,12 +252,12 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(LnReduceArgs a) {
   }
 }
 
-int g_ln_bwd_blocks = 512;  // vl_ln_debug_blocks(): A/B knob (256..512 measured equal, 1024 +0.1 ms, 2048 +0.7 ms per step)
+constexpr int LN_BWD_BLOCKS = 512;  // measured: 256..512 equal, 1024 +0.1 ms, 2048 +0.7 ms per step (partials traffic)
 int nblk_for(int64_t M) {
   // one partial row-set (3 x H floats) per workgroup: enough workgroups to keep >= 4 waves per SIMD in flight (the
   // kernel is a latency-bound stream, one row per wave at a time), few enough that the partials stay << the data
   int64_t n = (M + 3) / 4;
-  return (int)(n < g_ln_bwd_blocks ? n : g_ln_bwd_blocks);
+  return (int)(n < LN_BWD_BLOCKS ? n : LN_BWD_BLOCKS);
 }
 
 template <int NV>
@@ -320,7 +320,6 @@ extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addv
 }
 
 extern "C" int64_t vl_ln_bwd_ws_floats(int64_t M, int64_t H) { return (int64_t)nblk_for(M) * 3 * H; }
-extern "C" int vl_ln_debug_blocks(int n) { if (n >= 64 && n <= 8192) g_ln_bwd_blocks = n; return g_ln_bwd_blocks; }
 
 extern "C" int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd,
                          const float* gamma, const float* row_pre, const float* row_post, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta,

@@ -8,6 +8,7 @@ from . import _lib
 
 BF16 = torch.bfloat16
 EPI_F32, EPI_GELU_SPLIT, EPI_DGELU_BF16, EPI_BF16, EPI_SPLIT = 0, 1, 2, 3, 4
+GEMM_TILE = 0  # default `tile` of gemm_nt (micro-benchmarks set it; the native stack always uses the automatic choice)
 
 
 class _Launch(threading.local):
@@ -60,7 +61,7 @@ def _pld(t):
 
 
 def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=None, out32=None, out_hi=None,
-            out_lo=None, aux16=None):
+            out_lo=None, aux16=None, tile=0):
     """C[M,N] = A[M,K] . B[N,K]^T (+epilogue); operands are bf16 2-D tensors (row-major, ld = stride(0))."""
     pa, lda = _pld(a_hi)
     pb, ldb = _pld(b_hi)
@@ -72,9 +73,9 @@ def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=
     px = _pld(aux16)[0] if aux16 is not None else None
     if resid is not None:
         assert resid.stride(0) == ldc
-    _lib.check(_lib.lib().vl_gemm_nt(pa, pal, lda, pb, pbl, ldb, M, N, K, passes, epilogue, _p(bias),
-                                     _pld(resid)[0] if resid is not None else None, po32, ldc, ph, pl, px, ld16,
-                                     _stream()), "vl_gemm_nt")
+    _lib.check(_lib.lib().vl_gemm_nt_ex(pa, pal, lda, pb, pbl, ldb, M, N, K, passes, epilogue, _p(bias),
+                                        _pld(resid)[0] if resid is not None else None, po32, ldc, ph, pl, px, ld16,
+                                        tile or GEMM_TILE, _stream()), "vl_gemm_nt")
 
 
 def gemm_nt_splitk(a_hi, b_hi, M, N, K, out32, splits=None):
@@ -109,46 +110,6 @@ def gemm_tn_splitk(a, b, M, N, K, out32, splits=None):
         return False
     _lib.check(rc, "vl_gemm_tn_splitk")
     return True
-
-
-def gemm_tn_splitk_to(a, b, M, N, K, outs, accumulate=False, splits=None):
-    """outs[t] (+)= rows [t*M/len(outs), ...) of A[K,M]^T . B[K,N]: the weight gradient written straight into (views of)
-    the optimizer's gradient arena.  Returns False when the shape is outside the TN fast path."""
-    import ctypes
-    L = _lib.lib()
-    if splits is None:
-        splits = L.vl_gemm_splitk_plan(M, N, K)
-    ws = _tmp(torch.empty(M * N * splits, dtype=torch.float32, device=a.device))
-    pa, lda = _pld(a)
-    pb, ldb = _pld(b)
-    n = len(outs)
-    for o in outs:
-        assert o.is_contiguous() and o.dtype == torch.float32 and o.numel() == (M // n) * N
-    arr = (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs])
-    rc = L.vl_gemm_tn_splitk_to(pa, lda, pb, ldb, M, N, K, splits, _p(ws), ctypes.cast(arr, ctypes.c_void_p), n,
-                                1 if accumulate else 0, _stream())
-    if rc == -2:
-        return False
-    _lib.check(rc, "vl_gemm_tn_splitk_to")
-    return True
-
-
-def gemm_tn_grouped(problems, K, splits=0):
-    """One launch for several weight-gradient products sharing the batch dimension K:
-    problems = [(a [K,M] bf16, b [K,N] bf16, out [M,N] fp32, mask [M,N] fp32 or None), ...]  ->  out = a^T b (* mask)."""
-    import ctypes
-    n = len(problems)
-    arr = (ctypes.c_int64 * (10 * n))()
-    for i, (a, b, out, mask) in enumerate(problems):
-        pa, lda = _pld(a)
-        pb, ldb = _pld(b)
-        M, N = a.shape[1], b.shape[1]
-        assert a.shape[0] == K and b.shape[0] == K and tuple(out.shape) == (M, N) and out.stride(1) == 1
-        assert out.dtype == torch.float32 and (mask is None or (mask.dtype == torch.float32 and mask.stride() == out.stride()))
-        arr[10 * i:10 * i + 10] = [pa or 0, lda, pb or 0, ldb, out.data_ptr(), out.stride(0),
-                                   0 if mask is None else mask.data_ptr(), M, N, 0]
-    _lib.check(_lib.lib().vl_gemm_tn_grouped(ctypes.cast(arr, ctypes.c_void_p), n, K, splits, _stream()),
-               "vl_gemm_tn_grouped")
 
 
 def stack_fwd(desc, layer_begin, layer_end, stream_side=None):
@@ -203,16 +164,6 @@ def dw_grouped(problems, K, accumulate=False):
                                    0 if mask is None else _p(mask), M, N, 0]
     _lib.check(_lib.lib().vl_dw_grouped(ctypes.cast(arr, ctypes.c_void_p), n, K, 1 if accumulate else 0, _stream()),
                "vl_dw_grouped")
-
-
-def attn_fwd(qkv32, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed):
-    _lib.check(_lib.lib().vl_attn_fwd(_p(qkv32), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
-                                      float(p_drop), int(seed), _stream()), "vl_attn_fwd")
-
-
-def attn_bwd(qkv32, addmask, ctx_hi, ctx_lo, dctx32, lse, dqkv16, B, S, nh, dh, p_drop, seed):
-    _lib.check(_lib.lib().vl_attn_bwd(_p(qkv32), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(dctx32), _p(lse),
-                                      _p(dqkv16), B, S, nh, dh, float(p_drop), int(seed), _stream()), "vl_attn_bwd")
 
 
 def attn2_fwd(qkv_hi, qkv_lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed, nq=None):

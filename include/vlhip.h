@@ -29,9 +29,6 @@ extern "C" {
 
 int vl_version(void);
 const char* vl_last_error(void);
-int vl_debug_set(int key, int value); /* A/B knobs for benchmarking (not part of the drop-in surface): 1 = BN of the
-                                         single-barrier GEMM, 2 = force the generic GEMM, 7 = ping-pong GEMM (0 off, 1 auto,
-                                         2/3 = 256/192-wide tiles), 8 = ping-pong for 3-pass products */
 
 /* ------------------------------------------------------------------------------------------------------------
  * GEMM  C[M,N] = A[M,K] * B[N,K]^T  (+ epilogue), bf16 MFMA with fp32 accumulation.
@@ -51,6 +48,13 @@ enum {
 int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
                int64_t M, int64_t N, int64_t K, int passes, int epilogue, const float* bias, const float* resid32,
                float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream);
+/* The same with an explicit kernel / tile selection (tests, micro-benchmarks; the library keeps no tuning state):
+ * tile = 0 automatic (what vl_gemm_nt does) | 2 / 3 / 5 eight-wave ping-pong kernel with 256x256 / 256x192 / 224x256 tiles |
+ * 4 ping-pong, width by cost model only | 6 single-barrier kernel | 7 generic 128x128 kernel | 128 / 192 / 256
+ * single-barrier kernel of that width. */
+int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
+                  int64_t M, int64_t N, int64_t K, int passes, int epilogue, const float* bias, const float* resid32,
+                  float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, int tile, void* stream);
 
 /* Split-K form for the weight gradients dW[M,N] = A[M,K] * B[N,K]^T with K = B*S rows (bf16 single pass, fp32 out,
  * ld = N): `splits` K-ranges accumulate into fp32 slabs in `ws` (>= vl_gemm_splitk_ws_floats floats), then one
@@ -65,25 +69,6 @@ int vl_gemm_nt_splitk(const void* a_hi, int64_t lda, const void* b_hi, int64_t l
  * the fast path (K % 64, M >= 256, N >= 128, M/N multiples of 8): use vl_transpose_bf16 + vl_gemm_nt_splitk then. */
 int vl_gemm_tn_splitk(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, int64_t K,
                       int64_t splits, float* ws, float* out32, void* stream);
-/* ... with the rows of the result scattered over nout (1..4) contiguous destinations (`outs`: HOST array of device
- * pointers; rows [t*M/nout, (t+1)*M/nout) -> outs[t]), added to their contents when accumulate != 0: the engine points
- * them at the optimizer's flat gradient arena (packed Q/K/V gradient -> three parameters) instead of copying gradients.
- * ws: splits*M*N floats even for splits == 1. */
-int vl_gemm_tn_splitk_to(const void* a, int64_t lda, const void* b, int64_t ldb, int64_t M, int64_t N, int64_t K,
-                         int64_t splits, float* ws, float* const* outs, int64_t nout, int accumulate, void* stream);
-
-/* Grouped form of the same product (the four dW GEMMs of one transformer layer in ONE launch, no split-K slabs):
- * for each problem p, out_p[M_p, N_p] = A_p^T B_p (* mask_p) with A_p [K, M_p], B_p [K, N_p] row-major bf16 and K
- * (the batch rows, a multiple of 64) shared.  `probs` is a HOST array of nprob x VL_TN_FIELDS int64 values
- * {a, lda, b, ldb, out, ldo, mask (0 = none; fp32, same layout as out), M, N, 0}; M, N multiples of 8, nprob <= 8.
- * splits: 1 = one workgroup per 256 x 256 output tile; 2 = two K-halves atomically added into the (zeroed here)
- * output -- exactly two addends per element, so the sum is still deterministic; 0 = pick by tile count.
- * Replaces autograd's grad_weight = grad_output.t() @ input of nn.Linear (volta/encoders.py:229-246, 411-414,
- * 496-501, 553-556) and, with `mask`, the grad(weight_orig) = grad(weight) * weight_mask product of
- * torch.nn.utils.prune under train_task_sft.py:128-132. */
-#define VL_TN_FIELDS 10
-int vl_gemm_tn_grouped(const int64_t* probs, int64_t nprob, int64_t K, int64_t splits, void* stream);
-
 /* Weight gradients on K-major operands (csrc/dw.hip).  vl_transpose_blocked re-lays row-major bf16 activations
  * X [M, N] (ld) as XT[mb][n][mi] = X[64*mb + mi][n] (ceil(M/64) blocks of [N][64]; rows past M are zero; N a multiple of
  * 64): up to 8 matrices per launch; `tab` is a HOST array of n x VL_TR_FIELDS int64 {src, ld, N, dst, colsum_partial,
@@ -113,25 +98,15 @@ int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate
 int vl_colreduce_multi(const int64_t* tab, int64_t n, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
- * Fused V&L attention core over the single stream X = [text ; boxes]  (S = T + V <= 160, head dim 64).
+ * V&L attention core over the single stream X = [text ; boxes]  (S = T + V <= 160, head dim 64 or 32).
  * Replaces encoders.py:255-341: four gated score blocks, two concatenated softmaxes, four dropouts, four P.V
  * products == one multi-head attention with the additive key mask [t_mask ; v_mask] (encoders.py:978-995).
- * qkv32   [B*S, 3*nh*64] fp32, columns [Q | K | V], head h at h*64 inside each third.
- * addmask [B*S] fp32 additive key mask (0 or -10000).
- * ctx     (hi, lo) split [B*S, nh*64] -- attention output in [b, s, h*64+d] order (permute fused).
+ * addmask [B*S] fp32 additive key mask (0 or -10000; -inf for M3P).
+ * ctx     (hi, lo) split [B*S, nh*dh] -- attention output in [b, s, h*dh+d] order (permute fused).
  * lse     [B*nh*S] fp32 row log-sum-exp of the masked, scaled scores (saved for backward).
- * Dropout on the probabilities (p_drop, seed): keep-mask regenerated in backward from the same (seed).
- * exact fp32 arithmetic (v_mfma_f32_16x16x4_f32).
  * ------------------------------------------------------------------------------------------------------------ */
-int vl_attn_fwd(const float* qkv32, const float* addmask, void* ctx_hi, void* ctx_lo, float* lse, int64_t B,
-                int64_t S, int64_t nh, int64_t dh, float p_drop, uint64_t seed, void* stream);
-/* dctx32 [B*S, nh*64] fp32 -> dqkv16 [B*S, 3*nh*64] bf16 (same column layout as qkv32). */
-int vl_attn_bwd(const float* qkv32, const float* addmask, const void* ctx_hi, const void* ctx_lo,
-                const float* dctx32, const float* lse, void* dqkv16, int64_t B, int64_t S, int64_t nh, int64_t dh,
-                float p_drop, uint64_t seed, void* stream);
-
-/* The same op on the bf16 matrix pipe, fed by the (hi, lo) split of Q/K/V that the QKV projection writes with
- * VL_EPI_SPLIT (no fp32 copy of the projection goes through HBM):
+/* On the bf16 matrix pipe, fed by the (hi, lo) split of Q/K/V that the QKV projection writes with VL_EPI_SPLIT (no fp32
+ * copy of the projection goes through HBM):
  * qkv_hi / qkv_lo [B*S, 3*nh*64] bf16, columns [Q | K | V].  Forward: 3-term split products (fp32-grade, like the
  * projections around it); ctx (hi, lo) and lse as above.  Backward: single-pass bf16 on the hi halves (like every
  * other backward product): dctx16 bf16 -> dqkv16 bf16; delta = rowsum(P * dP) is computed in the kernel, so the saved
@@ -187,7 +162,6 @@ int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, int64_t
  * GEMM); column sums over the M rows: dgamma, dbeta, dbias (= colsum(dL/dy), the producing dense layer's bias
  * gradient; may be NULL).  partial_ws: >= vl_ln_bwd_ws_floats(M, H) floats of scratch. */
 int64_t vl_ln_bwd_ws_floats(int64_t M, int64_t H);
-int vl_ln_debug_blocks(int n); /* A/B knob: workgroups (= partial row-sets) of vl_ln_bwd; call before sizing the workspace */
 int vl_ln_bwd(const float* dy32, const float* z32, const float* mean, const float* rstd, const float* gamma,
               const float* row_pre, const float* row_post, float* dz32, void* dpre16, float* dpre32, float* dgamma, float* dbeta, float* dbias,
               float* partial_ws, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,

@@ -74,9 +74,8 @@ def test_gemm_pingpong_kernel(M, N, K, passes, width):
         ref = (a.double() @ b.double().t()).float()
     else:
         ref = (x.double() @ w.double().t()).float()
-    L = _lib.lib()
     try:
-        L.vl_debug_set(7, width)  # 2: 256 x 256 tiles, 3: 256 x 192 tiles
+        ops.GEMM_TILE = width  # 2: 256 x 256 tiles, 3: 256 x 192 tiles (per-call `tile` of vl_gemm_nt_ex)
         out = torch.full((M, N), float("nan"), device=DEV)
         ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, out32=out)
         if passes == 1:  # products of bf16 values are exact in fp32; only the accumulation order differs
@@ -96,7 +95,7 @@ def test_gemm_pingpong_kernel(M, N, K, passes, width):
         ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_SPLIT, out_hi=sh, out_lo=sl)
         eh, el = _split(out)
         assert torch.equal(sh, eh) and torch.equal(sl, el)
-        L.vl_debug_set(7, 0)  # the older single-barrier kernel adds the same products in the same k order
+        ops.GEMM_TILE = 6  # the older single-barrier kernel adds the same products in the same k order
         old = torch.empty_like(out)
         ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, out32=old)
         if passes == 1:
@@ -104,7 +103,7 @@ def test_gemm_pingpong_kernel(M, N, K, passes, width):
         else:
             torch.testing.assert_close(out, old, rtol=1e-5, atol=1e-5 * math.sqrt(K))
     finally:
-        L.vl_debug_set(7, 1)
+        ops.GEMM_TILE = 0
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (300, 200, 264), (1024, 2304, 768), (256, 1842, 768),
@@ -196,76 +195,6 @@ def _attn_ref(qkv, addmask, B, S, nh, keep=None):
     if keep is not None:
         p = p * keep
     return (p @ v).permute(0, 2, 1, 3).reshape(B * S, H), lse
-
-
-@pytest.mark.parametrize("B,T,V", [(3, 20, 36), (2, 40, 36), (2, 20, 100), (2, 40, 100), (1, 13, 20), (1, 60, 100)])
-def test_attention_forward_backward(B, T, V):
-    S, nh = T + V, 12
-    H = nh * 64
-    qkv = _rand(B * S, 3 * H, seed=12, scale=1.5)
-    m = torch.ones(B, S, device=DEV)
-    m[0, T - 5:T] = 0  # padded text tokens in sample 0
-    addmask = ((1 - m) * -10000.0).reshape(-1).contiguous()
-    ctx_hi = torch.empty(B * S, H, dtype=BF16, device=DEV)
-    ctx_lo = torch.empty_like(ctx_hi)
-    lse = torch.empty(B * nh * S, device=DEV)
-    ops.attn_fwd(qkv, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, 0.0, 1)
-    qd = qkv.double().requires_grad_(True)
-    ref, lse_ref = _attn_ref(qd, addmask.double().view(B, S), B, S, nh)
-    got = ctx_hi.double() + ctx_lo.double()
-    assert (got - ref.detach()).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
-    torch.testing.assert_close(lse.double().view(B, nh, S), lse_ref.detach(), rtol=1e-5, atol=1e-4)
-    dctx = _rand(B * S, H, seed=13)
-    ref.backward(dctx.double())
-    dqkv = torch.empty(B * S, 3 * H, dtype=BF16, device=DEV)
-    ops.attn_bwd(qkv, addmask, ctx_hi, ctx_lo, dctx, lse, dqkv, B, S, nh, 64, 0.0, 1)
-    g = qd.grad
-    err = (dqkv.double() - g).abs().max().item()
-    assert err <= 2 ** -7 * g.abs().max().item() + 1e-6, (err, g.abs().max().item())  # bf16 output rounding only
-
-
-def test_attention_dropout_is_consistent_between_forward_and_backward():
-    B, T, V, nh, p = 2, 20, 36, 4, 0.25
-    S, H = T + V, nh * 64
-    qkv = _rand(B * S, 3 * H, seed=14)
-    addmask = torch.zeros(B * S, device=DEV)
-    ctx_hi = torch.empty(B * S, H, dtype=BF16, device=DEV)
-    ctx_lo = torch.empty_like(ctx_hi)
-    lse = torch.empty(B * nh * S, device=DEV)
-    # recover the keep mask by using V = identity-like probes: run with V = one-hot keys is heavy; instead use
-    # linearity: ctx(p) with all-ones V column block gives rowsum(P*keep)
-    qkv2 = qkv.clone().view(B, S, 3, nh, 64)
-    qkv2[:, :, 2] = 1.0
-    qkv2 = qkv2.view(B * S, 3 * H).contiguous()
-    ops.attn_fwd(qkv2, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, p, 77)
-    rowsum = (ctx_hi.float() + ctx_lo.float()).view(B, S, nh, 64)[..., 0]
-    # E[rowsum] = 1, and it must not be identically 1 (dropout active) nor depend on d
-    assert abs(rowsum.mean().item() - 1.0) < 0.05
-    assert (rowsum - 1.0).abs().max().item() > 1e-3
-    # same seed -> same mask ; different seed -> different mask
-    c2h, c2l = torch.empty_like(ctx_hi), torch.empty_like(ctx_hi)
-    ops.attn_fwd(qkv2, addmask, c2h, c2l, lse, B, S, nh, 64, p, 77)
-    assert torch.equal(c2h, ctx_hi)
-    ops.attn_fwd(qkv2, addmask, c2h, c2l, lse, B, S, nh, 64, p, 78)
-    assert not torch.equal(c2h, ctx_hi)
-    # backward consistency via a directional finite difference of f(qkv) = sum(ctx * w)
-    ops.attn_fwd(qkv, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, p, 77)
-    w = _rand(B * S, H, seed=15)
-    dqkv = torch.empty(B * S, 3 * H, dtype=BF16, device=DEV)
-    ops.attn_bwd(qkv, addmask, ctx_hi, ctx_lo, w, lse, dqkv, B, S, nh, 64, p, 77)
-    # direction aligned with the gradient's signs: no cancellation in <dqkv, d>, so the bf16 rounding of dqkv (2^-9 per
-    # element) cannot masquerade as a mask mismatch
-    d = torch.sign(dqkv.float()) * (0.5 + torch.rand(B * S, 3 * H, generator=torch.Generator().manual_seed(16)).to(DEV))
-    eps = 2e-3
-
-    def f(x):
-        h_, l_ = torch.empty_like(ctx_hi), torch.empty_like(ctx_hi)
-        ops.attn_fwd(x.contiguous(), addmask, h_, l_, lse.clone(), B, S, nh, 64, p, 77)
-        return ((h_.double() + l_.double()) * w.double()).sum().item()
-
-    fd = (f(qkv + eps * d) - f(qkv - eps * d)) / (2 * eps)
-    an = (dqkv.double() * d.double()).sum().item()
-    assert abs(fd - an) <= 2e-2 * max(1.0, abs(fd)), (fd, an)
 
 
 @pytest.mark.parametrize("H", [256, 768, 1536])
@@ -485,50 +414,17 @@ def test_adamw_untouched_row_fast_path_is_bit_identical():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("K,splits", [(64, 1), (448, 1), (1024, 2), (14336, 0)])
-def test_gemm_tn_grouped(K, splits):
-    """Several dW = dY^T X products in one launch (ping-pong kernel with transposing LDS reads), masks in the epilogue."""
-    shapes = [(768, 768), (264, 136), (16, 520), (776, 1032)] if K < 2000 else [(768, 768), (2304, 768), (768, 3072)]
-    g = torch.Generator(device="cpu").manual_seed(K)
-    probs, refs = [], []
-    for i, (M, N) in enumerate(shapes):
-        wide = _rand(K, M + 24, seed=50 + i).to(BF16)
-        a = wide[:, 8:8 + M]  # a column slice: lda > M
-        b = _rand(K, N, seed=60 + i).to(BF16)
-        mask = (torch.rand(M, N, generator=g) > 0.3).float().to(DEV) if i % 2 == 0 else None
-        out = torch.full((M, N), float("nan"), device=DEV)
-        probs.append((a, b, out, mask))
-        ref = a.double().t() @ b.double()
-        refs.append((ref * mask.double() if mask is not None else ref).float())
-    ops.gemm_tn_grouped(probs, K, splits)
-    for (a, b, out, mask), ref in zip(probs, refs):
-        torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-4 * math.sqrt(max(K, 256) / 256))
-    first = [p[2].clone() for p in probs]
-    filler = torch.empty(64 << 20, device=DEV)
-    for it in range(6):  # deterministic (also with the two atomically added K-halves): any difference is a staging race
-        for p in probs:
-            p[2].fill_(float("nan"))
-        filler.normal_()
-        ops.gemm_tn_grouped(probs, K, splits)
-        for p, f in zip(probs, first):
-            assert torch.equal(p[2], f), it
-    with pytest.raises(RuntimeError, match="multiple of 64"):
-        ops.gemm_tn_grouped([(probs[0][0][:40], probs[0][1][:40], probs[0][2], None)], 40)
-
-
 @pytest.mark.parametrize("M,N,K", [(448, 512, 256), (300, 260, 192), (1000, 700, 64), (3584, 3072, 768), (2304, 520, 96)])
 def test_gemm_224_row_tiles(M, N, K):
     """The 224 x 256 ping-pong tile (FFN1 forward / its dX backward at B*S = 14336: 3 full rounds instead of 2.6) computes
     the same sums in the same order as the 256 x 256 tile: bit-identical outputs for both fused epilogues."""
-    from clg_vqa_amd import _lib
-    L = _lib.lib()
     x, w, bias = _rand(M, K, seed=70), _rand(N, K, seed=71, scale=0.1), _rand(N, seed=72)
     xh, xl = _split(x)
     wh, wl = _split(w)
     outs = {}
     try:
         for width in (2, 5):
-            L.vl_debug_set(7, width)
+            ops.GEMM_TILE = width
             u16 = torch.full((M, N), float("nan"), dtype=BF16, device=DEV)
             hh, hl, dh = torch.full_like(u16, float("nan")), torch.full_like(u16, float("nan")), torch.full_like(u16, float("nan"))
             if K % 32 == 0:
@@ -538,7 +434,7 @@ def test_gemm_224_row_tiles(M, N, K):
                 ops.gemm_nt(xh, None, wh, None, M, N, K, 1, EPI_DGELU_BF16, out_hi=dh, aux16=aux)
             outs[width] = (u16, hh, hl, dh)
     finally:
-        L.vl_debug_set(7, 1)
+        ops.GEMM_TILE = 0
     for a, b in zip(outs[2], outs[5]):
         assert torch.equal(a.view(torch.int16), b.view(torch.int16))  # bit patterns (NaN-filled where not computed)
     if K % 32 == 0:

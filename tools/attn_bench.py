@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Attention core A/B on the GPU box: fp32-pipe kernels (vl_attn_*) vs bf16-pipe kernels (vl_attn2_*), HIP-event timed."""
-import sys
+"""Attention core (vl_attn2_fwd / vl_attn2_bwd) on the GPU box, HIP-event timed with cold caches, against its HBM floor."""
 import os
+import sys
 
 import torch
 
@@ -33,8 +33,7 @@ def main():
         am = torch.zeros(M, device="cuda")
         ch, cl = torch.empty(M, H, dtype=BF16, device="cuda"), torch.empty(M, H, dtype=BF16, device="cuda")
         lse = torch.empty(B * nh * S, device="cuda")
-        d32 = torch.randn(M, H, device="cuda")
-        d16 = d32.to(BF16)
+        d16 = torch.randn(M, H, device="cuda").to(BF16)
         dq = torch.empty(M, 3 * H, dtype=BF16, device="cuda")
         junk = torch.empty(64 << 20, device="cuda")  # evict L2 / MALL between calls (256 MB)
 
@@ -44,13 +43,13 @@ def main():
                 fn()
             return g
         t_z = timeit(lambda: junk.zero_())
-        r = {}
+        fwd_mb = (2 * M * 3 * H * 2 + 2 * M * H * 2) / 1e6     # q,k,v (hi, lo) in, ctx (hi, lo) out
+        bwd_mb = (M * 3 * H * 2 + M * H * 2 + M * 3 * H * 2) / 1e6  # q,k,v hi + dctx in, dqkv out
         for p in (0.0, 0.1):
-            r["fwd32 p=%.1f" % p] = timeit(cold(lambda: ops.attn_fwd(qkv, am, ch, cl, lse, B, S, nh, 64, p, 1))) - t_z
-            r["fwd16 p=%.1f" % p] = timeit(cold(lambda: ops.attn2_fwd(hi, lo, am, ch, cl, lse, B, S, nh, 64, p, 1))) - t_z
-            r["bwd32 p=%.1f" % p] = timeit(cold(lambda: ops.attn_bwd(qkv, am, ch, cl, d32, lse, dq, B, S, nh, 64, p, 1))) - t_z
-            r["bwd16 p=%.1f" % p] = timeit(cold(lambda: ops.attn2_bwd(hi, am, d16, lse, dq, B, S, nh, 64, p, 1))) - t_z
-        print("B=%d S=%d: " % (B, S) + "  ".join("%s %.1f us" % kv for kv in r.items()), flush=True)
+            tf = timeit(cold(lambda: ops.attn2_fwd(hi, lo, am, ch, cl, lse, B, S, nh, 64, p, 1))) - t_z
+            tb = timeit(cold(lambda: ops.attn2_bwd(hi, am, d16, lse, dq, B, S, nh, 64, p, 1))) - t_z
+            print("B=%d S=%d p=%.1f: fwd %.1f us (%.2f TB/s of %.0f MB)  bwd %.1f us (%.2f TB/s of %.0f MB)" % (
+                B, S, p, tf, fwd_mb / tf, fwd_mb, tb, bwd_mb / tb, bwd_mb), flush=True)
 
 
 if __name__ == "__main__":
