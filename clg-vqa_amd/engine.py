@@ -350,6 +350,7 @@ class LayerStack(object):
             torch.cuda.current_stream().wait_stream(self._side)
             side_ptr = self._side.cuda_stream
         ops.stack_fwd(d, 0, len(self.specs), side_ptr)
+        ar.desc = d  # backward re-uses it (same pointers: nothing can move between a forward and its backward)
         L = len(self.specs)
         if ar.need_grad:
             ar.in_flight = True
@@ -362,7 +363,7 @@ class LayerStack(object):
         """dy [M,H] fp32 = dL/d(stack output).  Returns (dL/d(stack input), per-layer grads in LayerSpec.params order:
         None where the gradient went straight into the optimizer's arena)."""
         L, dev = len(self.specs), dy.device
-        d = self._descriptor(ar, pw_layers)
+        d = ar.desc
         d[VL["VL_ST_P_HID"]], d[VL["VL_ST_P_ATT"]] = _f32_bits(p_hid), _f32_bits(p_att)
         d[VL["VL_ST_SEED0"]] = seed0
         d[VL["VL_ST_ROW_POST"]] = 0 if row_post is None else ar.row_post.data_ptr()
