@@ -4,8 +4,9 @@ Reference semantics restated:
 * parameter grouping -- one group per tensor, ``lr = 1e-4 if "vil_" in name else base_lr``, weight decay 0 for names
   containing "bias" / "LayerNorm.bias" / "LayerNorm.weight" (volta/train_task.py:249-260);
 * ``pytorch_transformers.optimization.AdamW(lr, eps, betas, correct_bias)`` (call site train_task.py:264-268; the
-  package is an un-vendored dependency of the reference -> parity of its arithmetic is pinned by this repo's own
-  trajectory test against a plain-python restatement, "parity unpinned" by the reference);
+  package is an un-vendored dependency of the reference -> "parity unpinned" by the reference; its arithmetic is
+  restated in oracle/adamw_oracle.py and this kernel path is held to that restatement by
+  tests/test_gpu_trajectory.py (8 optimizer steps) and tests/test_gpu_kernels.py::test_adamw_and_sumsq);
 * ``WarmupLinearSchedule(warmup_steps, t_total)`` (train_task.py:271-274): lr multiplier step/warmup, then linear
   decay to 0 at t_total;
 * ``clip_grad_norm_(model.parameters(), 1.0)`` (train_task.py:330);

@@ -169,3 +169,96 @@ def test_dense_driver_resume(tmp_path):
     assert list(sd.keys()) == list(model.state_dict().keys())
     train_task.main(common + ["--num_epoch", "2", "--resume_file", os.path.join(out, "pytorch_ckpt_latest.tar")])
     assert os.path.exists(os.path.join(out, "pytorch_model_1.bin"))
+
+
+def _write_m3p_cfgs(tmp_path, vocab=300):
+    from clg_vqa_amd.config import m3p_base_config
+    cfg = dict(m3p_base_config(vocab), emb_dim=256, n_heads=4, n_layers=2, refine_layers=1, hidden_size=256, pooler_size=256,
+               clf_hidden_size=512)
+    cpath = tmp_path / "m3p_small.json"
+    cpath.write_text(json.dumps(cfg))
+    task = {"TASK15": dict(TASK_CFG["TASK15"], name="GQA", max_seq_length=40, max_region_num=36, batch_size=8,
+                           eval_batch_size=8, lr=4e-5, num_epoch=2, task_id=15, val_split="testdev")}
+    tpath = tmp_path / "tasks.yml"
+    tpath.write_text(yaml.safe_dump(task))
+    return str(cpath), str(tpath)
+
+
+def test_m3p_prune_then_sft_then_eval_drivers(tmp_path):
+    """--is_m3p through the same driver: the M3P prune list (train_task_prunning.py:258-307: 136 Linear weights incl. the
+    never-used modules), masks applied by name (train_task_sft.py:134-215), eval in the reference's result format with
+    answer STRINGS from a caller-supplied label2ans list and the GQA score against a truth file."""
+    cfg, tasks = _write_m3p_cfgs(tmp_path)
+    out_p = str(tmp_path / "prune")
+    common = ["--config_file", cfg, "--tasks_config_file", tasks, "--task", "15", "--steps_per_epoch", "3", "--is_m3p",
+              "--val_batches", "1", "--adam_correct_bias", "--clip_grad_norm", "1.0", "--weight_decay", "0.0001"]
+    train_task.main(["--mode", "prune", "--output_dir", out_p, "--num_epoch", "2"] + common)
+    m0 = torch.load(os.path.join(out_p, "mask_lt0.pt"), weights_only=True)
+    m1 = torch.load(os.path.join(out_p, "mask_best.pt"), weights_only=True)
+    names = sft.m3p_prunable_names(2)
+    assert len(names) == 2 * 10 + 10 + 6
+    assert set(k.replace(".weight_mask", "") for k in m1 if k.startswith("bert.encoder")) >= set(names)
+    tot = sum(m1[n + ".weight_mask"].numel() for n in names)
+    z0 = sum(int((m0[n + ".weight_mask"] == 0).sum()) for n in names)
+    z1 = sum(int((m1[n + ".weight_mask"] == 0).sum()) for n in names)
+    assert z0 == round(0.1 * tot) and z1 == z0 + round(0.1 * (tot - z0))
+    # the pooler is registered twice in the reference (bert.encoder.pooled_layer / bert.pooler): both keys carry the mask
+    assert torch.equal(m1["bert.pooler.dense.weight_mask"], m1["bert.encoder.pooled_layer.dense.weight_mask"])
+    out_s = str(tmp_path / "sft")
+    train_task.main(["--mode", "sft", "--output_dir", out_s, "--num_epoch", "1", "--from_pretrained",
+                     os.path.join(out_p, "pytorch_model_1.bin"), "--mask_dict_target",
+                     os.path.join(out_p, "mask_best.pt")] + common)
+    masked = torch.load(os.path.join(out_s, "pytorch_model_0.bin"), weights_only=True)
+    k0 = "bert.encoder.ffns.1.lin1.weight"
+    zero = m1["bert.encoder.ffns.1.lin1.weight_mask"] == 0
+    assert torch.all(masked[k0][zero] == 0) and float(masked[k0].abs().sum()) > 0
+    # eval: answer strings + score
+    label2ans = ["answer_%d" % i for i in range(1842)]
+    l2a = tmp_path / "label2ans.json"
+    l2a.write_text(json.dumps(label2ans))
+    out_e = str(tmp_path / "eval")
+    os.makedirs(out_e, exist_ok=True)
+    train_task.main(["--mode", "eval", "--output_dir", out_e, "--label2ans", str(l2a), "--from_pretrained",
+                     os.path.join(out_s, "pytorch_model_0.bin")] + common)
+    res = json.load(open(os.path.join(out_e, "testdev_result.json")))
+    assert len(res) == 8 and set(res[0]) == {"questionId", "prediction"} and res[0]["prediction"].startswith("answer_")
+    truth = {r["questionId"]: {"answer": r["prediction"] if i % 2 == 0 else "nope"} for i, r in enumerate(res)}
+    tf = tmp_path / "truth.json"
+    tf.write_text(json.dumps(truth))
+    score = train_task.main(["--mode", "eval", "--output_dir", out_e, "--label2ans", str(l2a), "--truth_file", str(tf),
+                             "--from_pretrained", os.path.join(out_s, "pytorch_model_0.bin")] + common)
+    assert score == 50.0
+
+
+def test_records_to_prefetcher_to_training_step():
+    """SURVEY 8f-3 end to end: records -> collate_records (box features, prior rows) -> pinned double-buffered H2D ->
+    ForwardModelsTrain on the native engine."""
+    from clg_vqa_amd import records, task_utils
+    from clg_vqa_amd.data import DevicePrefetcher
+    rs = np.random.RandomState(0)
+    C, V, T = 1842, 36, 20
+    sem = {}
+    table = np.zeros((C, C))  # dense prior table built directly (prior_table() is covered on CPU)
+    table[:] = rs.uniform(0.05, 1.0, size=(C, C))
+    np.fill_diagonal(table, 0.0)
+
+    def rec(i):
+        n = V if i % 3 else V - 5
+        x1 = rs.uniform(0, 300, n); y1 = rs.uniform(0, 200, n)
+        boxes = np.stack([x1, y1, x1 + rs.uniform(5, 200, n), y1 + rs.uniform(5, 150, n)], 1).astype(np.float32)
+        return dict(features=np.maximum(rs.randn(n, 2048), 0).astype(np.float32), boxes=boxes, img_w=640.0, img_h=480.0,
+                    tokens=[0] + rs.randint(5, 900, size=rs.randint(3, 30)).tolist() + [2], labels=[int(rs.randint(0, C))],
+                    scores=[1.0], question_id=i)
+
+    batches = [records.collate_records([rec(8 * b + i) for i in range(8)], T, V, 7, C, prior=table, batch_index=b)
+               for b in range(3)]
+    config = BertConfig.from_dict(uc2_cfg_dict(n_layers=1, vocab=1000))
+    model = BertForVLTasks(config, TASK_CFG, ["TASK15"]).cuda().train()
+    crit = torch.nn.CrossEntropyLoss()
+    n = 0
+    for dev_batch in DevicePrefetcher(iter(batches), "cuda", depth=2):
+        loss, score = task_utils.ForwardModelsTrain(config, TASK_CFG, "cuda", "TASK15", dev_batch, model, crit)
+        loss.backward()
+        assert torch.isfinite(loss)
+        n += 1
+    assert n == 3 and model.bert.embeddings.image_location_embeddings.weight.grad.abs().sum().item() > 0
