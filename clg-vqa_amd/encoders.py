@@ -365,6 +365,7 @@ class BertForVLTasks(PreTrainedModel):
         if image_attention_mask is None:
             image_attention_mask = torch.ones(input_imgs.size(0), input_imgs.size(1)).type_as(input_txt)
         params = self._engine.param_list()
+        self._engine.grad_mode = torch.is_grad_enabled()
         x = UC2TrunkFunction.apply(self._engine, self.training, input_txt, input_imgs, image_loc, token_type_ids,
                                    attention_mask, image_attention_mask, *params)
         pooled_output_t = self.bert.t_pooler(x)

@@ -448,6 +448,7 @@ class EngineBase(object):
         # train_utils.resume, so a resumed run continues the mask sequence instead of replaying it
         self.base_seed = (0x5EED ^ torch.initial_seed()) & 0xFFFFFFFF
         self.calls = 0
+        self.grad_mode = True  # torch.is_grad_enabled() at the model's call site (set by the module's forward)
 
     def mark_dirty(self):
         """Call after updating parameters through raw pointers (the fused optimizer does)."""
@@ -650,9 +651,10 @@ class TrunkFunction(torch.autograd.Function):
     def forward(ctx, engine, training, ids, feats, locs, seg, tmask, imask, *params):
         ops.set_stream(torch.cuda.current_stream().cuda_stream)  # one stream lookup for all launches of the pass
         try:
-            # (inside autograd.Function.forward grad mode is off: whether a backward can follow is what the inputs say)
+            # whether a backward can follow: the caller's grad mode (inside autograd.Function.forward it is always off,
+            # and ctx.needs_input_grad ignores torch.no_grad()) and whether any parameter wants a gradient
             out, sv = engine.forward(ids, feats, locs, seg, tmask, imask, training,
-                                     need_grad=any(ctx.needs_input_grad))
+                                     need_grad=engine.grad_mode and any(ctx.needs_input_grad))
         finally:
             ops.set_stream(None)
         ctx.engine = engine

@@ -298,6 +298,7 @@ class M3PForVLTasks(PreTrainedModel):
         if output_all_encoded_layers:
             raise NotImplementedError("output_all_encoded_layers for M3P")  # as the reference (encoders.py:1349)
         params = self._engine.param_list()
+        self._engine.grad_mode = torch.is_grad_enabled()
         x = TrunkFunction.apply(self._engine, self.training, input_txt, input_imgs, image_loc, token_type_ids,
                                 attention_mask, image_attention_mask, *params)
         pooled_output = self.dropout(self.bert.pooler(x))

@@ -308,3 +308,22 @@ def test_cpu_tensors_are_rejected_loudly():
     b = make_batch(2, vocab_size=100)
     with pytest.raises(RuntimeError, match="no CPU"):
         model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])
+
+
+def test_many_no_grad_forwards_reuse_one_inference_arena():
+    """An evaluation loop (torch.no_grad(), any number of batches) must not claim training arenas: the saved-activation
+    buffers of a training forward stay reserved only until its backward."""
+    config = BertConfig.from_dict(uc2_cfg_dict(n_layers=1, vocab=300))
+    model, _ = _build(config, seed=3)
+    b = tuple(t.cuda() for t in make_batch(2, vocab_size=300, seed=1))
+    model.train()
+    with torch.no_grad():
+        outs = [model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])[0] for _ in range(10)]
+    assert all(torch.isfinite(o).all() for o in outs)
+    arenas = model.engine.stack._arenas
+    assert all(not k[3] for k in arenas) and sum(len(v) for v in arenas.values()) == 1
+    # a training forward + backward in between still works, and a second training forward before the backward too
+    l1 = model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])[0].sum()
+    l2 = model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])[0].sum()
+    (l1 + l2).backward()
+    assert model.bert.t_pooler.dense.weight.grad.abs().sum().item() > 0
