@@ -252,7 +252,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(LnReduceArgs a) {
   }
 }
 
-constexpr int LN_BWD_BLOCKS = 512;  // measured: 256..512 equal, 1024 +0.1 ms, 2048 +0.7 ms per step (partials traffic)
+#ifndef VL_LN_BWD_BLOCKS
+#define VL_LN_BWD_BLOCKS 512  // measured: 256..512 equal, 1024 +0.1 ms, 2048 +0.7 ms per step (partials traffic)
+#endif
+constexpr int LN_BWD_BLOCKS = VL_LN_BWD_BLOCKS;
 int nblk_for(int64_t M) {
   // one partial row-set (3 x H floats) per workgroup: enough workgroups to keep >= 4 waves per SIMD in flight (the
   // kernel is a latency-bound stream, one row per wave at a time), few enough that the partials stay << the data
