@@ -242,6 +242,11 @@ def main():
         task_utils.FUSED_GQA_LOSS = False
     if os.environ.get("BENCH_DENSE_LAST", "0") == "1":  # A/B: the last layer computes all rows
         model.engine.stack.pooled_only = False
+    if os.environ.get("BENCH_MODULE_HEAD", "0") == "1":  # A/B: pooler / classifier module by module instead of head.py
+        model._task_head("TASK15").supported = False
+    if os.environ.get("BENCH_NO_SMALL_GEMM", "0") == "1":  # A/B: batch-sized products on the big-tile kernels
+        from clg_vqa_amd import ops as _ops
+        _ops.SMALL_GEMM = False
     if os.environ.get("BENCH_NO_OVERLAP", "0") == "1":  # A/B: weight-gradient work on the main stream
         model.engine.stack.overlap_dw = False
     model.train()

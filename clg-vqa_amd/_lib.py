@@ -19,7 +19,8 @@ _SIGS = {
     "vl_gemm_nt": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, P, P, P, c_int64,
                            P, P, P, c_int64, P]),
     "vl_gemm_nt_ex": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, P, P, P, c_int64,
-                              P, P, P, c_int64, c_int, P]),
+                              P, P, P, c_int64, c_int, P, c_int64, P]),
+    "vl_gemm_small_ws_floats": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_splitk_plan": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_splitk_ws_floats": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_nt_splitk": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P]),
@@ -54,6 +55,8 @@ _SIGS = {
     "vl_imp_select": (c_int, [P, P, P, c_int64, c_int64, P, P]),
     "vl_weight_prep_multi": (c_int, [P, c_int64, c_int64, P]),
     "vl_split_f32": (c_int, [P, P, P, c_int64, P]),
+    "vl_act_fwd": (c_int, [P, c_int64, c_int64, c_int, c_float, c_uint64, P, P, P, c_int64, P]),
+    "vl_act_bwd": (c_int, [P, P, c_int64, c_int64, c_int, c_float, c_uint64, P, P, c_int64, P]),
     "vl_transpose_bf16": (c_int, [P, P, c_int64, c_int64, c_int64, c_int64, P]),
     "vl_colsum_ws_floats": (c_int64, [c_int64, c_int64]),
     "vl_colsum_bf16": (c_int, [P, c_int64, c_int64, c_int64, P, P, P]),

@@ -33,6 +33,8 @@ namespace {
 // Kernel / tile selection is a per-call argument (`tile` of vl_gemm_nt_ex; the library holds no mutable state):
 //   0 automatic | 2 / 3 / 5 ping-pong kernel with 256x256 / 256x192 / 224x256 tiles | 4 ping-pong, cost model only
 //   6 single-barrier kernel (automatic width) | 7 generic 128x128 kernel | 128 / 192 / 256 single-barrier kernel of that width
+//   8 small-M path (64x64 tiles + split K through the caller's workspace); automatic for shapes whose big tiles would
+//     leave 3/4 of the chip idle, when the caller passes a workspace
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
@@ -49,6 +51,7 @@ struct GemmArgs {
   int splits;                   // TN kernel: number of K-ranges (1-D grid over splits x tiles)
   int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
   int tile;                     // host-side kernel / tile selection (see above); not read by the kernels
+  float* ws; long ws_floats;    // host-side: caller-owned workspace of the small-M path (may be NULL)
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -837,6 +840,162 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// small-M path (M = batch products: the pooled rows of the last layer, pooler / classifier head): with M = 256 the big
+// tiles give 4-16 workgroups, each walking the whole K with two K-tiles in flight -- pure memory latency (141 us for
+// the pooled FFN2, 3.6 GFLOP).  Here: 64 x 64 tile (4 waves as 2 x 2, wave tile 32 x 32), BK = 64, register-staged
+// prefetch, and the K range split over blockIdx.y so that ~500 workgroups (several per CU) have all of the operands
+// in flight at once; every workgroup stores its raw fp32 partial tile into slab y of a caller-owned workspace and a
+// second launch sums the slabs in a fixed order (deterministic) and applies the epilogue.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int SB = 64;
+constexpr int STILE_BYTES = SB * BK * 2;  // 8 KiB per operand tile
+template <int NSPLIT>
+__global__ __launch_bounds__(256) void gemm_small_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA_hi = smem;
+  unsigned char* sB_hi = smem + STILE_BYTES;
+  unsigned char* sA_lo = smem + 2 * STILE_BYTES;
+  unsigned char* sB_lo = smem + 3 * STILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tm = blockIdx.x / p.tiles_n, tn = blockIdx.x - tm * p.tiles_n;
+  const int row0 = tm * SB, col0 = tn * SB;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int kbeg = blockIdx.y * p.k_len;
+  const int kend = min(p.K, kbeg + p.k_len);
+  uint4 ra_hi[2], rb_hi[2], ra_lo[2], rb_lo[2];
+  auto load_tile = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int row = c >> 3, k = k0 + ((c & 7) << 3);
+      ra_hi[i] = load_chunk(p.a_hi, p.lda, row0 + row, p.M, k, kend);
+      rb_hi[i] = load_chunk(p.b_hi, p.ldb, col0 + row, p.N, k, kend);
+      if (NSPLIT == 3) {
+        ra_lo[i] = load_chunk(p.a_lo, p.lda, row0 + row, p.M, k, kend);
+        rb_lo[i] = load_chunk(p.b_lo, p.ldb, col0 + row, p.N, k, kend);
+      }
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256;
+      const int off = lds_off(c >> 3, c & 7);
+      *reinterpret_cast<uint4*>(sA_hi + off) = ra_hi[i];
+      *reinterpret_cast<uint4*>(sB_hi + off) = rb_hi[i];
+      if (NSPLIT == 3) {
+        *reinterpret_cast<uint4*>(sA_lo + off) = ra_lo[i];
+        *reinterpret_cast<uint4*>(sB_lo + off) = rb_lo[i];
+      }
+    }
+  };
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) load_tile(kbeg);
+  const int frow = lane & 15, fk = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (kt + 1 < nk) load_tile(kbeg + (kt + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a_h[2], b_h[2], a_l[2], b_l[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra = wm * 32 + i * 16 + frow, rb = wn * 32 + i * 16 + frow;
+        const int oa = lds_off(ra, kk * 4 + fk), ob = lds_off(rb, kk * 4 + fk);
+        a_h[i] = *reinterpret_cast<const bf16x8*>(sA_hi + oa);
+        b_h[i] = *reinterpret_cast<const bf16x8*>(sB_hi + ob);
+        if (NSPLIT == 3) {
+          a_l[i] = *reinterpret_cast<const bf16x8*>(sA_lo + oa);
+          b_l[i] = *reinterpret_cast<const bf16x8*>(sB_lo + ob);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (NSPLIT == 3) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_h[j], a_l[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_l[j], a_h[i], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b_h[j], a_h[i], acc[i][j], 0, 0, 0);
+        }
+    }
+  }
+  // raw partial tile -> slab blockIdx.y of the workspace [splits][M][ldc], ldc = N rounded up to 4 (D^T layout: a lane
+  // holds 4 consecutive columns of row m)
+  float* out = p.out32 + (long)blockIdx.y * p.slab_stride;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = row0 + wm * 32 + i * 16 + (lane & 15);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n0 = col0 + wn * 32 + j * 16 + 4 * (lane >> 4);
+      if (n0 < p.ldc)
+        *reinterpret_cast<float4*>(out + (long)m * p.ldc + n0) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    }
+  }
+}
+
+// sum of the slabs (fixed order) + the epilogue; one thread per 4 consecutive columns of a row
+template <int EPI>
+__global__ __launch_bounds__(256) void small_epilogue_kernel(GemmArgs p, const float* __restrict__ ws, int splits, long slab,
+                                                             int ldw) {
+  const long n4 = ldw >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)p.M * n4) return;
+  const int m = (int)(idx / n4), n0 = (int)(idx - (long)m * n4) * 4;
+  const float* src = ws + (long)m * ldw + n0;
+  float4 t = *reinterpret_cast<const float4*>(src);
+  for (int s = 1; s < splits; ++s) {
+    const float4 u = *reinterpret_cast<const float4*>(src + (long)s * slab);
+    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+  }
+  epilogue_store4<EPI>(p, p.out32, m, n0, f32x4{t.x, t.y, t.z, t.w});
+}
+
+// K ranges of the small path: ~512 workgroups, at least 2 K-tiles per workgroup
+struct SmallPlan { int splits; int k_len; int ldw; };
+inline SmallPlan small_plan(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + SB - 1) / SB) * ((N + SB - 1) / SB), steps = (K + BK - 1) / BK;
+  int64_t splits = 512 / tiles;
+  if (splits > steps / 2) splits = steps / 2;
+  if (splits < 1) splits = 1;
+  const int64_t per = (steps + splits - 1) / splits;
+  SmallPlan pl;
+  pl.k_len = (int)(per * BK);
+  pl.splits = (int)((steps + per - 1) / per);
+  pl.ldw = (int)((N + 3) / 4 * 4);
+  return pl;
+}
+// the small path pays while the big tiles cannot fill ~40 % of the chip (measured switch-over, tools/small_gemm_bench.py:
+// M = 2048 x N = 3072 and M = 4096 x N = 2304 are ties, below that the small path wins by 1.3-7x)
+inline bool small_shape(int64_t M, int64_t N) { return ((M + 255) / 256) * ((N + 191) / 192) < 100; }
+
+template <int NSPLIT, int EPI>
+int launch_small(const GemmArgs& a, float* ws, hipStream_t stream) {
+  const SmallPlan pl = small_plan(a.M, a.N, a.K);
+  const size_t lds = (NSPLIT == 3 ? 4 : 2) * STILE_BYTES;
+  GemmArgs s = a;
+  s.tiles_m = (a.M + SB - 1) / SB; s.tiles_n = (a.N + SB - 1) / SB;
+  s.out32 = ws; s.ldc = pl.ldw; s.k_len = pl.k_len; s.slab_stride = (long)a.M * pl.ldw;
+  hipLaunchKernelGGL((gemm_small_kernel<NSPLIT>), dim3(s.tiles_m * s.tiles_n, pl.splits), dim3(256), lds, stream, s);
+  VL_CHECK_LAUNCH("vl_gemm_nt(small)");
+  const long n = (long)a.M * (pl.ldw / 4);
+  hipLaunchKernelGGL((small_epilogue_kernel<EPI>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, ws, pl.splits,
+                     (long)a.M * pl.ldw, pl.ldw);
+  VL_CHECK_LAUNCH("vl_gemm_nt(small epilogue)");
+  return 0;
+}
+
 template <int NSPLIT, int EPI>
 int launch(const GemmArgs& a, hipStream_t stream, int splits = 1) {
   const size_t lds = (NSPLIT == 3 ? 4 : 2) * TILE_BYTES;
@@ -915,6 +1074,11 @@ inline bool fast_ok(int64_t M, int64_t K, int64_t k_len, int passes, int tile) {
 
 template <int NSPLIT, int EPI>
 int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
+  if (splits == 1 && a.ws && (a.tile == 8 || (a.tile == 0 && small_shape(a.M, a.N)))) {
+    const SmallPlan pl = small_plan(a.M, a.N, a.K);
+    if ((long)pl.splits * a.M * pl.ldw <= a.ws_floats) return launch_small<NSPLIT, EPI>(a, a.ws, s);
+    if (a.tile == 8) return vl_set_error(-1, "vl_gemm_nt_ex: workspace too small for the small-M path");
+  }
   const int g_pingpong = (a.tile == 0) ? 1 : (a.tile == 2 || a.tile == 3 || a.tile == 4 || a.tile == 5) ? a.tile : 0;
   if (splits == 1 && g_pingpong && a.M >= 256 && a.N >= 192 && (a.K % (NSPLIT == 3 ? 32 : 64)) == 0) {
     // tile shape by "rounds over the 256 CUs x tile area" (key 7: 1 = automatic, 2 / 3 / 5 = force 256x256 / 256x192 /
@@ -962,16 +1126,17 @@ extern "C" int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const
                           const float* bias, const float* resid32, float* out32, int64_t ldc, void* out_hi,
                           void* out_lo, void* aux16, int64_t ld16, void* stream) {
   return vl_gemm_nt_ex(a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, passes, epilogue, bias, resid32, out32, ldc, out_hi, out_lo,
-                       aux16, ld16, 0, stream);
+                       aux16, ld16, 0, nullptr, 0, stream);
 }
 
 // ... with an explicit kernel / tile selection (tests and micro-benchmarks; 0 = the automatic choice of vl_gemm_nt)
 extern "C" int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                              int64_t ldb, int64_t M, int64_t N, int64_t K, int passes, int epilogue,
                              const float* bias, const float* resid32, float* out32, int64_t ldc, void* out_hi,
-                             void* out_lo, void* aux16, int64_t ld16, int tile, void* stream) {
+                             void* out_lo, void* aux16, int64_t ld16, int tile, float* ws, int64_t ws_floats,
+                             void* stream) {
   VL_CHECK_ARG(passes == 1 || passes == 3, "vl_gemm_nt: passes must be 1 or 3 (got %d)", passes);
-  VL_CHECK_ARG(tile == 0 || (tile >= 2 && tile <= 7) || tile == 128 || tile == 192 || tile == 256,
+  VL_CHECK_ARG(tile == 0 || (tile >= 2 && tile <= 8) || tile == 128 || tile == 192 || tile == 256,
                "vl_gemm_nt_ex: unknown tile selection %d", tile);
   VL_CHECK_ARG(M > 0 && N > 0 && K > 0 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30),
                "vl_gemm_nt: bad dims M=%lld N=%lld K=%lld", (long long)M, (long long)N, (long long)K);
@@ -991,7 +1156,7 @@ extern "C" int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, co
     VL_CHECK_ARG(epilogue != VL_EPI_DGELU_BF16 || aux16, "vl_gemm_nt: DGELU needs aux16");
     VL_CHECK_ARG(!resid32, "vl_gemm_nt: resid32 only with the F32 epilogue");
   }
-  GemmArgs a;
+  GemmArgs a{};
   a.a_hi = (const bf16_raw*)a_hi; a.a_lo = (const bf16_raw*)a_lo;
   a.b_hi = (const bf16_raw*)b_hi; a.b_lo = (const bf16_raw*)b_lo;
   a.lda = lda; a.ldb = ldb; a.M = (int)M; a.N = (int)N; a.K = (int)K;
@@ -999,12 +1164,22 @@ extern "C" int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, co
   a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.aux16 = (bf16_raw*)aux16; a.ld16 = ld16;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   a.k_len = (int)K; a.slab_stride = 0; a.tile = tile;
+  VL_CHECK_ARG(tile != 8 || ws, "vl_gemm_nt_ex: tile 8 (small-M path) needs a workspace");
+  VL_CHECK_ARG(!ws || ((reinterpret_cast<uintptr_t>(ws) & 15u) == 0 && ws_floats >= 0), "vl_gemm_nt_ex: workspace must be 16-byte aligned");
+  a.ws = ws; a.ws_floats = ws_floats;
   a.vec8 = (ld16 & 7) == 0 && aligned16(bias) && aligned16(out_hi) && aligned16(out_lo) && aligned16(aux16);
   a.vec = ((ldc | ld16) & 3) == 0 && aligned16(bias) && aligned16(resid32) && aligned16(out32) &&
           ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo) |
             reinterpret_cast<uintptr_t>(aux16)) & 7) == 0;
   hipStream_t s = (hipStream_t)stream;
   return passes == 3 ? dispatch_epi<3>(epilogue, a, s) : dispatch_epi<1>(epilogue, a, s);
+}
+
+// floats of workspace the small-M path wants for this shape (0: the shape never takes it)
+extern "C" int64_t vl_gemm_small_ws_floats(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const SmallPlan pl = small_plan(M, N, K);
+  return (int64_t)pl.splits * M * pl.ldw;
 }
 
 // Split-K variant for the weight-gradient products dW[N_out,K_in] = dY^T X, whose reduction dimension is the

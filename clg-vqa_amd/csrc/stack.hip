@@ -48,13 +48,15 @@ void prof_end(int64_t* pair, int64_t tag, int64_t flops, void* stream) {
   pair[3] = flops;
 }
 
-// vl_gemm_nt, optionally bracketed by a caller-owned event pair (descriptor field VL_ST_PROF)
-int gemm(int64_t* prof, const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
+// vl_gemm_nt, optionally bracketed by a caller-owned event pair (descriptor field VL_ST_PROF); B-row products of the
+// pooled-row mode take the small-M path through the descriptor's workspace (VL_ST_SMALL_WS)
+struct GemmCtx { int64_t* prof; float* ws; int64_t ws_floats; };
+int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
          int64_t M, int64_t N, int64_t K, int passes, int epi, const float* bias, const float* resid, float* out32,
          int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream) {
-  int64_t* pair = prof_begin(prof, stream);
-  const int rc = vl_gemm_nt(a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, passes, epi, bias, resid, out32, ldc, out_hi, out_lo,
-                            aux16, ld16, stream);
+  int64_t* pair = prof_begin(g.prof, stream);
+  const int rc = vl_gemm_nt_ex(a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, passes, epi, bias, resid, out32, ldc, out_hi, out_lo,
+                               aux16, ld16, 0, g.ws, g.ws_floats, stream);
   prof_end(pair, passes * 16 + epi, 2 * M * N * K, stream);
   return rc;
 }
@@ -109,6 +111,7 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
   const float* addmask = ptr<const float>(d[VL_ST_ADDMASK]);
   const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
   int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
+  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS]};
   hipStream_t ss = stream_side ? (hipStream_t)stream_side : (hipStream_t)stream;
   hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);
   for (int64_t l = layer_begin; l < layer_end; ++l) {
@@ -129,17 +132,17 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
                                   ptr<float>(y[VL_LY_LSE]), B, S, nh, H / nh, nq, p_att, seed_of(d[VL_ST_SEED0], s3), stream));
       prof_end(pair, VL_PROF_TAG_QKV_ATTN, 2 * M * 3 * H * H + 4 * B * nq * S * H, stream);
     }
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_CTX_HI]), ptr<void>(y[VL_LY_CTX_LO]), H, ptr<void>(y[VL_LY_WO_HI]), ptr<void>(y[VL_LY_WO_LO]), H,
+    VL_TRY(gemm(gc, ptr<void>(y[VL_LY_CTX_HI]), ptr<void>(y[VL_LY_CTX_LO]), H, ptr<void>(y[VL_LY_WO_HI]), ptr<void>(y[VL_LY_WO_LO]), H,
                 R, H, H, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_BO]), nullptr, ptr<float>(y[VL_LY_Z1]), H, nullptr, nullptr,
                 nullptr, 0, stream));
     VL_TRY(vl_ln_fwd(ptr<float>(y[VL_LY_Z1]), ptr<const float>(y[VL_LY_X32]), nullptr, 1, nullptr, nullptr,
                      ptr<const float>(y[VL_LY_LN1_G]), ptr<const float>(y[VL_LY_LN1_B]), eps, ptr<float>(y[VL_LY_X1_32]),
                      ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), ptr<float>(y[VL_LY_MEAN1]), ptr<float>(y[VL_LY_RSTD1]),
                      R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 1), os, os, stream));
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), H, ptr<void>(y[VL_LY_W1_HI]), ptr<void>(y[VL_LY_W1_LO]), H,
+    VL_TRY(gemm(gc, ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), H, ptr<void>(y[VL_LY_W1_HI]), ptr<void>(y[VL_LY_W1_LO]), H,
                 R, I, H, 3, VL_EPI_GELU_SPLIT, ptr<const float>(y[VL_LY_B1]), nullptr, nullptr, 0, ptr<void>(y[VL_LY_H_HI]),
                 ptr<void>(y[VL_LY_H_LO]), ptr<void>(y[VL_LY_U16]), I, stream));
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_H_HI]), ptr<void>(y[VL_LY_H_LO]), I, ptr<void>(y[VL_LY_W2_HI]), ptr<void>(y[VL_LY_W2_LO]), I,
+    VL_TRY(gemm(gc, ptr<void>(y[VL_LY_H_HI]), ptr<void>(y[VL_LY_H_LO]), I, ptr<void>(y[VL_LY_W2_HI]), ptr<void>(y[VL_LY_W2_LO]), I,
                 R, H, I, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_B2]), nullptr, ptr<float>(y[VL_LY_Z2]), H, nullptr, nullptr,
                 nullptr, 0, stream));
     VL_TRY(vl_ln_fwd(ptr<float>(y[VL_LY_Z2]), ptr<const float>(y[VL_LY_X1_32]), nullptr, 1, nullptr, row_post,
@@ -192,6 +195,7 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
   const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
   const int accumulate = (int)d[VL_ST_ACCUMULATE];
   int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
+  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS]};
   hipStream_t sm = (hipStream_t)stream_main;
   hipStream_t ss = stream_side ? (hipStream_t)stream_side : sm;
   hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);
@@ -207,15 +211,15 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
                      ptr<const float>(y[VL_LY_RSTD2]), ptr<const float>(y[VL_LY_LN2_G]), nullptr, row_post, ptr<float>(y[VL_LY_DZ2]),
                      ptr<void>(y[VL_LY_DT2]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS2]), R, H, R, 0, 0, p_hid, 0.f,
                      seed_of(d[VL_ST_SEED0], s3 + 2), os, sm));
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT2]), nullptr, H, ptr<void>(y[VL_LY_W2_T]), nullptr, H, R, I, H, 1, VL_EPI_DGELU_BF16,
+    VL_TRY(gemm(gc, ptr<void>(y[VL_LY_DT2]), nullptr, H, ptr<void>(y[VL_LY_W2_T]), nullptr, H, R, I, H, 1, VL_EPI_DGELU_BF16,
                 nullptr, nullptr, nullptr, 0, ptr<void>(y[VL_LY_DU16]), nullptr, ptr<void>(y[VL_LY_U16]), I, sm));
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DU16]), nullptr, I, ptr<void>(y[VL_LY_W1_T]), nullptr, I, R, H, I, 1, VL_EPI_F32, nullptr,
+    VL_TRY(gemm(gc, ptr<void>(y[VL_LY_DU16]), nullptr, I, ptr<void>(y[VL_LY_W1_T]), nullptr, I, R, H, I, 1, VL_EPI_F32, nullptr,
                 ptr<const float>(y[VL_LY_DZ2]), ptr<float>(y[VL_LY_DX1]), H, nullptr, nullptr, nullptr, 0, sm));
     VL_TRY(vl_ln_bwd(ptr<const float>(y[VL_LY_DX1]), ptr<const float>(y[VL_LY_Z1]), ptr<const float>(y[VL_LY_MEAN1]),
                      ptr<const float>(y[VL_LY_RSTD1]), ptr<const float>(y[VL_LY_LN1_G]), nullptr, nullptr, ptr<float>(y[VL_LY_DZ1]),
                      ptr<void>(y[VL_LY_DT1]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS1]), R, H, R, 0, 0, p_hid, 0.f,
                      seed_of(d[VL_ST_SEED0], s3 + 1), os, sm));
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DT1]), nullptr, H, ptr<void>(y[VL_LY_WO_T]), nullptr, H, R, H, H, 1, VL_EPI_BF16, nullptr,
+    VL_TRY(gemm(gc, ptr<void>(y[VL_LY_DT1]), nullptr, H, ptr<void>(y[VL_LY_WO_T]), nullptr, H, R, H, H, 1, VL_EPI_BF16, nullptr,
                 nullptr, nullptr, 0, ptr<void>(y[VL_LY_DCTX16]), nullptr, nullptr, H, sm));
     VL_TRY(vl_attn2_bwd(ptr<void>(y[VL_LY_QKV_HI]), addmask, ptr<void>(y[VL_LY_DCTX16]), ptr<const float>(y[VL_LY_LSE]),
                         ptr<void>(y[VL_LY_DQKV]), B, S, nh, H / nh, nq, p_att, seed_of(d[VL_ST_SEED0], s3), sm));
@@ -226,7 +230,7 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
     }
     // dL/dX = dQKV W_qkv + dz1 (the residual branch); in the pooled-row mode dz1 only has the B live rows: they are
     // added to rows b * S afterwards (one fp32 add per element either way: bit-identical to the dense epilogue)
-    VL_TRY(gemm(prof, ptr<void>(y[VL_LY_DQKV]), nullptr, 3 * H, ptr<void>(y[VL_LY_WQKV_T]), nullptr, 3 * H, M, H, 3 * H, 1, VL_EPI_F32,
+    VL_TRY(gemm(gc, ptr<void>(y[VL_LY_DQKV]), nullptr, 3 * H, ptr<void>(y[VL_LY_WQKV_T]), nullptr, 3 * H, M, H, 3 * H, 1, VL_EPI_F32,
                 nullptr, pooled ? nullptr : ptr<const float>(y[VL_LY_DZ1]), ptr<float>(y[VL_LY_DX]), H, nullptr, nullptr, nullptr, 0,
                 sm));
     if (pooled)

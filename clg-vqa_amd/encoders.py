@@ -109,6 +109,9 @@ class VLLinear(nn.Linear):
     """nn.Linear holder; ``forward`` (used by the head only) runs the native GEMM."""
 
     def _vl_prepared(self, device):
+        pw = self.__dict__.get("_vl_engine_pw")  # head Linears: prepared by the engine's per-step launch
+        if pw is not None and pw.hi.device == device:
+            return pw
         pw = getattr(self, "_vl_pw", None)
         if pw is None or pw.hi.device != device:
             pw = PreparedWeight([self], device)
@@ -368,7 +371,19 @@ class BertForVLTasks(PreTrainedModel):
         self._engine.grad_mode = torch.is_grad_enabled()
         x = UC2TrunkFunction.apply(self._engine, self.training, input_txt, input_imgs, image_loc, token_type_ids,
                                    attention_mask, image_attention_mask, *params)
-        pooled_output_t = self.bert.t_pooler(x)
-        pooled_output = self.dropout(pooled_output_t)  # fusion_method == "text" (encoders.py:1238-1239)
-        vil_prediction = self.clfs_dict[task_id](pooled_output)
+        head = self._task_head(task_id)
+        if head.supported:  # pooler -> dropout -> classifier as one native autograd node (head.py)
+            vil_prediction = head(x, self.training)
+        else:
+            pooled_output_t = self.bert.t_pooler(x)
+            pooled_output = self.dropout(pooled_output_t)  # fusion_method == "text" (encoders.py:1238-1239)
+            vil_prediction = self.clfs_dict[task_id](pooled_output)
         return vil_prediction, None, None, ([None], [None])
+
+    def _task_head(self, task_id):
+        heads = self.__dict__.setdefault("_vl_heads", {})
+        if task_id not in heads:
+            from .head import TaskHead
+            heads[task_id] = TaskHead(self._engine, self.bert.t_pooler.dense, self.config.fusion_act, self.dropout,
+                                      self.clfs_dict[task_id])
+        return heads[task_id]

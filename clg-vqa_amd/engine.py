@@ -208,8 +208,14 @@ class StackArena(object):
         self.addmask, self.row_post = f32(M), f32(M)
         self.rows0 = torch.arange(B, dtype=torch.int64, device=device) * S  # the pooled row of every sample
         self.in_flight = False  # a training forward whose backward has not run yet owns the saved activations
+        # workspace of the small-M GEMM path: the B-row products of the pooled last layer (and every product of a batch
+        # with few rows); launches of one stream share it
+        lib = _lib.lib()
+        shapes = [(B, H, H), (B, I, H), (B, H, I)]
+        if M <= 8192:
+            shapes += [(M, 3 * H, H), (M, H, H), (M, I, H), (M, H, I), (M, H, 3 * H)]
+        self.small_ws = f32(max(lib.vl_gemm_small_ws_floats(*s_) for s_ in shapes))
         if need_grad:
-            lib = _lib.lib()
             self.dbuf = f32(2, M, H)
             self.dz2, self.dx1, self.dz1, self.dctx16 = f32(M, H), f32(M, H), f32(M, H), b16(M, H)
             self.dt2, self.du16, self.dt1, self.dqkv = b16(L, M, H), b16(L, M, I), b16(L, M, H), b16(L, M, 3 * H)
@@ -293,6 +299,8 @@ class LayerStack(object):
         d[VL["VL_ST_EPS"]] = _f32_bits(self.eps)
         d[VL["VL_ST_ADDMASK"]] = ar.addmask.data_ptr()
         d[VL["VL_ST_ROWS0"]] = ar.rows0.data_ptr()
+        if ops.SMALL_GEMM:
+            d[VL["VL_ST_SMALL_WS"]], d[VL["VL_ST_SMALL_WS_FLOATS"]] = ar.small_ws.data_ptr(), ar.small_ws.numel()
         if ar.need_grad:
             d[VL["VL_ST_EV_FORK"]] = ar.fork.cuda_event
             for k in ("t_dqkv", "t_dt1", "t_du", "t_dt2", "cs_qkv", "cs_u"):
@@ -449,6 +457,8 @@ class EngineBase(object):
         self.base_seed = (0x5EED ^ torch.initial_seed()) & 0xFFFFFFFF
         self.calls = 0
         self.grad_mode = True  # torch.is_grad_enabled() at the model's call site (set by the module's forward)
+        self._seed0 = 0
+        self._last_arena = None
 
     def mark_dirty(self):
         """Call after updating parameters through raw pointers (the fused optimizer does)."""
@@ -466,15 +476,41 @@ class EngineBase(object):
         """(seed0, site -> seed): site s draws from seed0 * 4096 + s (the native stack uses sites 16 l + 3 .. 16 l + 5)."""
         self.calls += 1
         seed0 = (self.base_seed * 0x9E3779B1 + self.calls * 0x10001) & 0x7FFFFFFFFFFF
+        self._seed0 = seed0
         return seed0, (lambda site: (seed0 * 4096 + site) & 0xFFFFFFFFFFFFFFFF)
+
+    def last_seed(self, site):
+        """Seed of `site` for the forward pass that is being built (the task head draws its dropout mask from it)."""
+        return (self._seed0 * 4096 + site) & 0xFFFFFFFFFFFFFFFF
+
+    def head_linears(self):
+        """Leaf Linears of the task heads: prepared by the same launch as the trunk's weights."""
+        return []
+
+    def pooled_split(self, x):
+        """(hi, lo) bf16 operand form of the pooled rows when `x` is the output of this engine's last forward in the
+        pooled-row mode (the last LayerNorm of the stack wrote it next to the fp32 rows), else None."""
+        ar = self._last_arena
+        if ar is None or not getattr(ar, "pooled", False):
+            return None
+        L = ar.L
+        out = ar.x32[L % 2]
+        if x.data_ptr() != out.data_ptr() or x.shape[0] != ar.B or x.numel() != ar.B * out.shape[-1]:
+            return None
+        hi = (ar.x_hi[L] if ar.need_grad else ar.x_hi[L % 2])[:ar.B]
+        return hi, ar.x_lo[L % 2][:ar.B]
 
     def prepared(self, device):
         if self._prepared is None or self._prepared["device"] != device:
+            heads = self.head_linears()
             self._prepared = dict(device=device, img=PreparedWeight([self.image_linear()], device, need_t=False),
-                                  layers=self.stack.make_prepared(device))
+                                  layers=self.stack.make_prepared(device),
+                                  head=[PreparedWeight([lin], device) for lin in heads])
+            for lin, p in zip(heads, self._prepared["head"]):
+                object.__setattr__(lin, "_vl_engine_pw", p)  # VLLinear._vl_prepared returns it
             self._dirty = True
         pw = self._prepared
-        all_pw = [pw["img"]] + [lw[k] for lw in pw["layers"] for k in ("qkv", "o", "w1", "w2")]
+        all_pw = [pw["img"]] + [lw[k] for lw in pw["layers"] for k in ("qkv", "o", "w1", "w2")] + pw["head"]
         explicit = self._dirty  # set by the optimizer every step: no need to fingerprint versions to find that out
         if explicit or any(p._key() != p.key for p in all_pw):
             # the device table only depends on where the source weights / masks live: compare those pointers first
@@ -517,6 +553,12 @@ class UC2Engine(EngineBase):
     def image_linear(self):
         return self.model.bert.embeddings.image_embeddings
 
+    def head_linears(self):
+        lins = [self.model.bert.t_pooler.dense]
+        for clf in self.model.clfs_dict.values():
+            lins += [clf.logit_fc[0], clf.logit_fc[3]]
+        return lins
+
     # ---- parameters ------------------------------------------------------------------------------------------
     def param_list(self):
         """Differentiable tensors of the trunk in a fixed order (backward returns grads in this order)."""
@@ -555,6 +597,7 @@ class UC2Engine(EngineBase):
         feats2 = feats.contiguous().view(BV, F)
         locs2 = locs.contiguous().view(BV, L)
         ar = self.stack.arena(B, S, dev, need_grad)
+        self._last_arena = ar
         sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, seed0=seed0, ids=ids, seg=seg,
                   locs=locs2, pw=pw, arena=ar)
 

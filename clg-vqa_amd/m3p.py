@@ -20,6 +20,7 @@ from torch import nn
 from . import ops
 from .config import M3PConfig
 from .encoders import GeLU, PreTrainedModel, SimpleClassifier, VLLinear  # noqa: F401
+from .head import TaskHead
 from .engine import BF16, EPI_F32, EngineBase, LayerSpec, LayerStack, TrunkFunction, dw_gemm, linear_params
 
 N_MAX_POSITIONS = 514
@@ -143,6 +144,12 @@ class M3PEngine(EngineBase):
     def image_linear(self):
         return self.model.bert.encoder.image_embeddings.image_embeddings
 
+    def head_linears(self):
+        lins = [self.model.bert.pooler.dense]
+        for clf in self.model.clfs_dict.values():
+            lins += [clf.logit_fc[0], clf.logit_fc[3]]
+        return lins
+
     def param_list(self):
         e = self.model.bert.encoder
         ie = e.image_embeddings
@@ -169,6 +176,7 @@ class M3PEngine(EngineBase):
         seed0, seed = self.next_seed()
         pw = self.prepared(dev)
         ar = self.stack.arena(B, S, dev, need_grad)
+        self._last_arena = ar
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
         ids = ids.contiguous()
@@ -301,5 +309,14 @@ class M3PForVLTasks(PreTrainedModel):
         self._engine.grad_mode = torch.is_grad_enabled()
         x = TrunkFunction.apply(self._engine, self.training, input_txt, input_imgs, image_loc, token_type_ids,
                                 attention_mask, image_attention_mask, *params)
+        head = self._task_head(task_id)
+        if head.supported:
+            return head(x, self.training), None, None, None
         pooled_output = self.dropout(self.bert.pooler(x))
         return self.clfs_dict[task_id](pooled_output), None, None, None
+
+    def _task_head(self, task_id):
+        heads = self.__dict__.setdefault("_vl_heads", {})
+        if task_id not in heads:
+            heads[task_id] = TaskHead(self._engine, self.bert.pooler.dense, "tanh", self.dropout, self.clfs_dict[task_id])
+        return heads[task_id]

@@ -60,9 +60,25 @@ def _pld(t):
     return t.data_ptr(), t.stride(0)
 
 
+_SMALL_WS = {}
+SMALL_GEMM = True  # A/B knob (bench.py BENCH_NO_SMALL_GEMM): False = batch-sized products on the big-tile kernels
+
+
+def small_ws(device, floats, stream):
+    """Grow-only fp32 workspace of the small-M GEMM path, one per (device, launch stream): launches on one stream are
+    ordered, so consecutive products may share it."""
+    key = (str(device), stream)
+    t = _SMALL_WS.get(key)
+    if t is None or t.numel() < floats:
+        t = torch.empty(max(floats, 1 << 20), dtype=torch.float32, device=device)
+        _SMALL_WS[key] = t
+    return t
+
+
 def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=None, out32=None, out_hi=None,
             out_lo=None, aux16=None, tile=0):
-    """C[M,N] = A[M,K] . B[N,K]^T (+epilogue); operands are bf16 2-D tensors (row-major, ld = stride(0))."""
+    """C[M,N] = A[M,K] . B[N,K]^T (+epilogue); operands are bf16 2-D tensors (row-major, ld = stride(0)).  Products
+    with a small M (the batch-sized products of the head) get a workspace and take the library's small-M path."""
     pa, lda = _pld(a_hi)
     pb, ldb = _pld(b_hi)
     pal = _pld(a_lo)[0] if a_lo is not None else None
@@ -73,9 +89,15 @@ def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=
     px = _pld(aux16)[0] if aux16 is not None else None
     if resid is not None:
         assert resid.stride(0) == ldc
-    _lib.check(_lib.lib().vl_gemm_nt_ex(pa, pal, lda, pb, pbl, ldb, M, N, K, passes, epilogue, _p(bias),
-                                        _pld(resid)[0] if resid is not None else None, po32, ldc, ph, pl, px, ld16,
-                                        tile or GEMM_TILE, _stream()), "vl_gemm_nt")
+    L = _lib.lib()
+    tile = tile or GEMM_TILE
+    ws, nws, st = None, 0, _stream()
+    if M <= 8192 and tile in (0, 8) and (SMALL_GEMM or tile == 8):
+        nws = L.vl_gemm_small_ws_floats(M, N, K)
+        ws = small_ws(a_hi.device, nws, st).data_ptr()
+    _lib.check(L.vl_gemm_nt_ex(pa, pal, lda, pb, pbl, ldb, M, N, K, passes, epilogue, _p(bias),
+                               _pld(resid)[0] if resid is not None else None, po32, ldc, ph, pl, px, ld16,
+                               tile, ws, nws, st), "vl_gemm_nt")
 
 
 def gemm_nt_splitk(a_hi, b_hi, M, N, K, out32, splits=None):
@@ -251,6 +273,24 @@ def imp_select(w_flat, mask_flat, new_mask_flat, k):
 
 def weight_prep_multi(table_dev, ndesc, total_tiles):
     _lib.check(_lib.lib().vl_weight_prep_multi(_p(table_dev), ndesc, total_tiles, _stream()), "vl_weight_prep_multi")
+
+
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_GELU = 0, 1, 2, 3
+
+
+def act_fwd(z32, M, N, act, p_drop, seed, out32=None, out_hi=None, out_lo=None):
+    """y = dropout(act(z)) -> fp32 and / or its (hi, lo) split with zero pad columns up to out_hi.stride(0)."""
+    ph, ld16 = _pld(out_hi)
+    assert out_lo is None or out_lo.stride(0) == ld16
+    _lib.check(_lib.lib().vl_act_fwd(_p(z32), M, N, act, float(p_drop), int(seed), _p(out32), ph,
+                                     _pld(out_lo)[0] if out_lo is not None else None, ld16, _stream()), "vl_act_fwd")
+
+
+def act_bwd(dy32, z32, M, N, act, p_drop, seed, dz32=None, dz16=None):
+    """dz = dy * dropout mask * act'(z) -> fp32 and / or bf16 with zero pad columns up to dz16.stride(0)."""
+    ph, ld16 = _pld(dz16)
+    _lib.check(_lib.lib().vl_act_bwd(_p(dy32), _p(z32), M, N, act, float(p_drop), int(seed), _p(dz32), ph, ld16,
+                                     _stream()), "vl_act_bwd")
 
 
 def split_f32(x32, hi, lo=None):

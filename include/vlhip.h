@@ -51,10 +51,17 @@ int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi
 /* The same with an explicit kernel / tile selection (tests, micro-benchmarks; the library keeps no tuning state):
  * tile = 0 automatic (what vl_gemm_nt does) | 2 / 3 / 5 eight-wave ping-pong kernel with 256x256 / 256x192 / 224x256 tiles |
  * 4 ping-pong, width by cost model only | 6 single-barrier kernel | 7 generic 128x128 kernel | 128 / 192 / 256
- * single-barrier kernel of that width. */
+ * single-barrier kernel of that width | 8 small-M path.
+ * ws / ws_floats (may be NULL / 0): caller-owned fp32 workspace of the SMALL-M PATH -- products whose M is the batch (the
+ * pooled rows of the last layer, pooler, classifier: encoders.py:597-608, :788-815) would run on 4-16 of the 256 CUs
+ * with the big tiles, bound by memory latency; with a workspace of >= vl_gemm_small_ws_floats(M, N, K) floats they run
+ * as 64x64 tiles x K ranges (~500 workgroups, raw partial tiles into the workspace) + one launch that sums the ranges
+ * in a fixed order and applies the epilogue.  Automatic (tile 0) when fewer than 100 big tiles would be launched. */
 int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
                   int64_t M, int64_t N, int64_t K, int passes, int epilogue, const float* bias, const float* resid32,
-                  float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, int tile, void* stream);
+                  float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, int tile,
+                  float* ws, int64_t ws_floats, void* stream);
+int64_t vl_gemm_small_ws_floats(int64_t M, int64_t N, int64_t K);
 
 /* Split-K form for the weight gradients dW[M,N] = A[M,K] * B[N,K]^T with K = B*S rows (bf16 single pass, fp32 out,
  * ld = N): `splits` K-ranges accumulate into fp32 slabs in `ws` (>= vl_gemm_splitk_ws_floats floats), then one
@@ -231,6 +238,8 @@ enum {
   VL_ST_ROWS0 = 27, /* int64 [B] device array {0, S, 2S, ...}: the live rows (pooled-row mode) */
   VL_ST_TR_BLOCKS_FWD = 28, /* workgroup caps of the K-major re-layout launches (0 = default) */
   VL_ST_TR_BLOCKS_BWD = 29,
+  VL_ST_SMALL_WS = 30, /* fp32 workspace of the small-M GEMM path (vl_gemm_nt_ex) for the B-row products of the pooled-row mode; 0 = none */
+  VL_ST_SMALL_WS_FLOATS = 31,
   VL_ST_FIELDS = 32
 };
 enum {
@@ -374,6 +383,24 @@ int vl_loc_linear_fwd(const float* loc, const float* w, const float* b, float* y
 /* dw [H,L], db [H] are ACCUMULATED with atomics: zero them first. */
 int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db, int64_t R, int64_t L, int64_t H,
                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Element-wise stages of the pooler / classifier head on [M = batch, N] fp32 tensors (contiguous, ld = N).
+ * Replaces: BertTextPooler's ReLU (volta/volta/encoders.py:597-608), M3P BertPooler's tanh
+ * (volta/volta/m3p/m3p_transformer.py:548-560), nn.Dropout on the pooled vector (encoders.py:1238-1239) and
+ * SimpleClassifier's GeLU (encoders.py:788-815, :131-137), each with autograd's replay.
+ *   vl_act_fwd: y = dropout_p(act(z)) -> out32 [M,N] (may be NULL) and / or its (hi, lo) bf16 split (out_lo may be NULL),
+ *               leading dimension ld16 >= N, columns [N, ld16) written as zeros (the operand form of the next GEMM).
+ *   vl_act_bwd: dz = dy * dropout_mask_p * act'(z) -> dz32 (may be NULL) and / or bf16 dz16 (ld16, zero pad columns):
+ *               the operand of the next dX GEMM and of the weight-gradient path; act = VL_ACT_NONE is the plain
+ *               cast + pad (z32 may then be NULL).
+ * Dropout masks are counter-based (seed, element index m*N + n), regenerated in backward.
+ * ------------------------------------------------------------------------------------------------------------ */
+enum { VL_ACT_NONE = 0, VL_ACT_RELU = 1, VL_ACT_TANH = 2, VL_ACT_GELU = 3 };
+int vl_act_fwd(const float* z32, int64_t M, int64_t N, int act, float p_drop, uint64_t seed, float* out32, void* out_hi,
+               void* out_lo, int64_t ld16, void* stream);
+int vl_act_bwd(const float* dy32, const float* z32, int64_t M, int64_t N, int act, float p_drop, uint64_t seed, float* dz32,
+               void* dz16, int64_t ld16, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GQA loss with semantic prior, its score and d(loss)/d(logits) in one launch (csrc/loss.hip).

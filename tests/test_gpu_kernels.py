@@ -128,6 +128,49 @@ def test_gemm_three_pass_is_fp32_grade(M, N, K):
     assert err < err1 / 20, (err, err1)
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (256, 3072, 768), (256, 768, 768), (256, 1842, 1536), (256, 1024, 768),
+                                   (128, 768, 768), (8, 1842, 1536), (70, 100, 72), (1000, 768, 3072), (2, 128, 128)])
+@pytest.mark.parametrize("passes", [1, 3])
+def test_gemm_small_m_path(M, N, K, passes):
+    """tile 8: 64 x 64 tiles x K ranges through a workspace + the slab-sum / epilogue launch (the batch-sized products of
+    the pooled last layer and the head).  Against fp64, every epilogue against the generic kernel's, and repeatable."""
+    x, w = _rand(M, K, seed=50), _rand(N, K, seed=51, scale=0.05)
+    bias, resid = _rand(N, seed=52), _rand(M, N, seed=53)
+    a, al = _split(x)
+    b, bl = _split(w)
+    if passes == 1:
+        al = bl = None
+        ref = a.double() @ b.double().t() + bias.double() + resid.double()
+    else:
+        ref = x.double() @ w.double().t() + bias.double() + resid.double()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, bias=bias, resid=resid, out32=out, tile=8)
+    err = (out.double() - ref).abs().max().item()
+    scale = (x.double().abs() @ w.double().abs().t()).max().item()
+    assert err <= 6e-5 * scale / math.sqrt(K) + 1e-5, (err, scale)
+    again = torch.full((M, N), float("nan"), device=DEV)
+    ops.gemm_nt(a, al, b, bl, M, N, K, passes, EPI_F32, bias=bias, resid=resid, out32=again, tile=8)
+    assert torch.equal(out, again)
+    Np = (N + 7) // 8 * 8  # 16-bit outputs need a leading dimension the vector stores can use
+    for epi in (EPI_SPLIT, EPI_BF16, EPI_GELU_SPLIT, EPI_DGELU_BF16):
+        got, want = [], []
+        for tile, dst in ((8, got), (7, want)):
+            hi, lo = torch.zeros(M, Np, dtype=BF16, device=DEV), torch.zeros(M, Np, dtype=BF16, device=DEV)
+            aux = torch.zeros(M, Np, dtype=BF16, device=DEV)
+            if epi == EPI_DGELU_BF16:
+                aux[:, :N] = _rand(M, N, seed=54).to(BF16)
+            ops.gemm_nt(a, al, b, bl, M, N, K, passes, epi, bias=None if epi == EPI_DGELU_BF16 else bias,
+                        out_hi=hi, out_lo=lo if epi in (EPI_SPLIT, EPI_GELU_SPLIT) else None,
+                        aux16=aux if epi in (EPI_GELU_SPLIT, EPI_DGELU_BF16) else None, tile=tile)
+            dst += [hi.float(), lo.float(), aux.float()]
+        # different accumulation order: fp32 values differ by ~1e-5, i.e. at most one bf16 rounding step in `hi` / `aux`
+        # (`lo` alone is not comparable: it is the residual of whichever way `hi` rounded)
+        for g, w_ in ((got[0], want[0]), (got[2], want[2])):
+            assert ((g - w_).abs() <= 2.0 ** -7 * w_.abs() + 1e-4).all()
+        torch.testing.assert_close(got[0] + got[1], want[0] + want[1], rtol=2 ** -7 if epi in (EPI_BF16, EPI_DGELU_BF16) else 1e-4,
+                                   atol=1e-4)
+
+
 @pytest.mark.parametrize("M,N,K", [(768, 768, 14336), (2304, 768, 14336), (768, 3072, 4096), (200, 136, 1000), (128, 128, 64)])
 def test_gemm_splitk(M, N, K):
     a = _rand(M, K, seed=40).to(BF16)
@@ -776,3 +819,42 @@ def test_qkv_attention_entry_points_equal_the_two_step_sequence():
     ops.attn2_bwd(q_hi, addmask, d16, lse, rdq, B, S, nh, dh, 0.0, 1)
     ops.gemm_nt(rdq, None, wt, None, M, H, 3 * H, 1, EPI_F32, resid=resid, out32=rdx)
     assert torch.equal(dqkv, rdq) and torch.equal(dx, rdx)
+
+
+@pytest.mark.parametrize("M,N", [(256, 768), (256, 1842), (8, 130), (3, 1536)])
+def test_head_activation_kernels(M, N):
+    """vl_act_fwd / vl_act_bwd: activation + dropout + operand split (forward), mask * activation' + cast + zero pad
+    (backward) against torch, and the same dropout mask in both directions."""
+    z = _rand(M, N, seed=60)
+    dy = _rand(M, N, seed=61)
+    ld = (N + 63) // 64 * 64
+    acts = ((ops.ACT_RELU, torch.relu), (ops.ACT_TANH, torch.tanh), (ops.ACT_GELU, _gelu), (ops.ACT_NONE, lambda t: t))
+    for act, fn in acts:
+        for p in (0.0, 0.25):
+            seed = 1234 + act
+            ones = torch.ones(M, N, device=DEV)
+            mask = torch.empty(M, N, device=DEV)
+            ops.act_fwd(ones, M, N, ops.ACT_NONE, p, seed, out32=mask)  # keep-scale of every element at this seed
+            if p == 0.0:
+                assert torch.equal(mask, ones)
+            else:
+                assert set(mask.unique().tolist()) <= {0.0, 1.0 / (1.0 - p)} or \
+                    ((mask == 0) | ((mask - 1.0 / (1.0 - p)).abs() < 1e-6)).all()
+                if M * N > 10000:
+                    assert abs((mask == 0).float().mean().item() - p) < 0.01
+            out32 = torch.full((M, N), float("nan"), device=DEV)
+            hi = torch.full((M, ld), float("nan"), dtype=BF16, device=DEV)
+            lo = torch.full((M, ld), float("nan"), dtype=BF16, device=DEV)
+            ops.act_fwd(z, M, N, act, p, seed, out32=out32, out_hi=hi, out_lo=lo)
+            zz = z.clone().requires_grad_(True)
+            ref = fn(zz) * mask
+            torch.testing.assert_close(out32, ref.detach(), rtol=1e-5, atol=2e-6)
+            eh, el = _split(out32)
+            assert torch.equal(hi[:, :N], eh) and torch.equal(lo[:, :N], el)
+            assert (hi[:, N:].float() == 0).all() and (lo[:, N:].float() == 0).all()
+            ref.backward(dy)
+            dz32 = torch.full((M, N), float("nan"), device=DEV)
+            dz16 = torch.full((M, ld), float("nan"), dtype=BF16, device=DEV)
+            ops.act_bwd(dy, None if act == ops.ACT_NONE else z, M, N, act, p, seed, dz32=dz32, dz16=dz16)
+            torch.testing.assert_close(dz32, zz.grad, rtol=1e-5, atol=2e-6)
+            assert torch.equal(dz16[:, :N], dz32.to(BF16)) and (dz16[:, N:].float() == 0).all()
