@@ -785,6 +785,16 @@ def test_qkv_attention_entry_points_equal_the_two_step_sequence():
     """vl_qkv_attention_fwd / _bwd == projection GEMM (split epilogue) + attention, and attention backward +
     dX GEMM, bit for bit; and fp32-grade against fp64 math."""
     from clg_vqa_amd import _lib
+    monkey_small = ops.SMALL_GEMM
+    ops.SMALL_GEMM = False  # the entry points take no workspace: compare with the same (big-tile) kernel choice
+    try:
+        _qkv_attention_entry_points()
+    finally:
+        ops.SMALL_GEMM = monkey_small
+
+
+def _qkv_attention_entry_points():
+    from clg_vqa_amd import _lib
     B, S, nh, dh = 2, 56, 12, 64
     H, M = nh * dh, B * S
     x, w = _rand(M, H, seed=101), _rand(3 * H, H, seed=102, scale=0.05)

@@ -235,12 +235,26 @@ def test_c5_sft_masks_with_100_boxes_together():
         assert (gr - r).norm().item() <= GRAD_REL_L2 * r.norm().item(), n
 
 
+@pytest.mark.parametrize("small_gemm", [False, True])
 @pytest.mark.parametrize("B,T,V,train", [(8, 20, 36, True), (3, 7, 9, True), (5, 40, 100, False)])
-def test_pooled_row_mode_equals_the_dense_run(B, T, V, train):
+def test_pooled_row_mode_equals_the_dense_run(B, T, V, train, small_gemm):
     """The last layer only computes the pooled row of every sample (the head reads hidden_states[:, 0],
-    encoders.py:597-608).  Against the dense run -- same weights, batch, dropout seeds (dropout ON) -- the logits are
-    bit-equal and every gradient agrees to fp32 rounding (the weight gradients of the last layer sum the same non-zero
-    addends in a different grouping: the dense run also adds the exact zeros of the dead rows)."""
+    encoders.py:597-608).  Against the dense run -- same weights, batch, dropout seeds (dropout ON) -- with the same GEMM
+    kernel choice in both runs (small_gemm False: the big-tile kernels, whose K order does not depend on M) the logits
+    are bit-equal and every gradient agrees to fp32 rounding (the weight gradients of the last layer sum the same
+    non-zero addends in a different grouping: the dense run also adds the exact zeros of the dead rows).  With the small-M
+    GEMM path on (the shipped configuration) the B-row products split K differently from the M-row ones: the same
+    addends in another order, i.e. fp32 rounding in the logits too."""
+    from clg_vqa_amd import ops
+    saved = ops.SMALL_GEMM
+    ops.SMALL_GEMM = small_gemm
+    try:
+        _pooled_vs_dense(B, T, V, train, bit_equal=not small_gemm)
+    finally:
+        ops.SMALL_GEMM = saved
+
+
+def _pooled_vs_dense(B, T, V, train, bit_equal):
     config = BertConfig.from_dict(uc2_cfg_dict(n_layers=3, vocab=800))
     model, _ = _build(config, seed=29)
     batch = make_batch(B, seq_len=T, num_boxes=V, vocab_size=800, seed=300 + B)
@@ -257,8 +271,12 @@ def test_pooled_row_mode_equals_the_dense_run(B, T, V, train):
             b = tuple(t.cuda() for t in batch)
             logits = model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])[0].clone()
         res[mode] = (float(loss), logits, {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
-    assert res[False][0] == res[True][0]
-    assert torch.equal(res[False][1], res[True][1])
+    if bit_equal:
+        assert res[False][0] == res[True][0]
+        assert torch.equal(res[False][1], res[True][1])
+    else:
+        assert abs(res[False][0] - res[True][0]) <= 1e-5 * abs(res[False][0])
+        torch.testing.assert_close(res[False][1], res[True][1], rtol=0, atol=5e-5)  # measured 1.1e-5; parity bound 1e-3
     worst = (0.0, None)
     for n, g in res[False][2].items():
         g2 = res[True][2][n]
@@ -267,7 +285,7 @@ def test_pooled_row_mode_equals_the_dense_run(B, T, V, train):
             worst = (rel, n)
         if n.endswith("attention_self.key.bias"):
             continue
-        assert rel <= 2e-6, (n, rel)
+        assert rel <= (2e-6 if bit_equal else 5e-3)  # bf16 backward operands: an fp32 rounding flip becomes a bf16 one (measured 9e-4), (n, rel)
     print("pooled vs dense (B=%d S=%d train=%s): loss equal, logits bit-equal, worst gradient rel diff %.2e at %s" % (
         B, T + V, train, worst[0], worst[1]))
 
