@@ -70,6 +70,24 @@ int check_header(const char* fn, const int64_t* d) {
   return 0;
 }
 
+// K-major images of layer l's X operands {layer input, attention context, LayerNorm-1 output, GELU output} for the
+// weight-gradient GEMMs (dw.hip)
+int x_images(const int64_t* d, int64_t l, int64_t max_blocks, hipStream_t ss) {
+  const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I], L = d[VL_ST_NLAYERS], M = B * S;
+  const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
+  const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;
+  const int64_t tr[4 * VL_TR_FIELDS] = {
+      y[VL_LY_X_HI], H, H, y[VL_LY_T_X], 0, 0,
+      y[VL_LY_CTX_HI], H, H, y[VL_LY_T_CTX], 0, 0,
+      y[VL_LY_X1_HI], H, H, y[VL_LY_T_X1], 0, 0,
+      y[VL_LY_H_HI], I, I, y[VL_LY_T_H], 0, 0};
+  if (pooled) {  // the layer input has M rows, the other three only the B live ones
+    VL_TRY(vl_transpose_blocked(tr, 1, M, max_blocks, ss));
+    return vl_transpose_blocked(tr + VL_TR_FIELDS, 3, B, max_blocks, ss);
+  }
+  return vl_transpose_blocked(tr, 4, M, max_blocks, ss);
+}
+
 }  // namespace
 
 // The op north_star names -- QKV projection + softmax(QK^T)V over the mixed (token, box) sequence -- as one entry point.
@@ -150,12 +168,13 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
                      ptr<void>(y[VL_LY_OUT_HI]), ptr<void>(y[VL_LY_OUT_LO]), ptr<float>(y[VL_LY_MEAN2]), ptr<float>(y[VL_LY_RSTD2]),
                      R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 2), os, 1, stream));
   }
-  // training: the K-major images of every layer's X operands {layer input, attention context, LayerNorm-1 output, GELU
-  // output} for the weight-gradient GEMMs of backward.  They are written on the side stream once the LAST layer of the
-  // stack has been enqueued: the head / loss / head-backward phase that follows is ~50 tiny latency-bound kernels
-  // (~0.6 ms during which the chip is idle), so this HBM-bound re-layout runs there instead of beside the GEMMs (written
-  // layer by layer beside the forward GEMMs it cost the QKV projection +40 %; written in backward it is 1.3 ms more work on
-  // the stream that already limits the backward GEMMs)
+  // training: the K-major images of the layers' X operands {layer input, attention context, LayerNorm-1 output, GELU
+  // output} for the weight-gradient GEMMs of backward.  Those of the top layers (all but the bottom VL_ST_TR_BWD_LAYERS)
+  // are written on the side stream once the LAST layer of the stack has been enqueued, i.e. under the task head / loss
+  // (tiny latency-bound kernels, the chip is otherwise idle); the others in backward, on the side stream ahead of the
+  // layer's own re-layout.  History: written layer by layer beside the forward GEMMs the re-layout cost the QKV
+  // projection +40 % (net zero); all 12 layers under the head was best while the head was ~75 eager launches (0.6 ms);
+  // with the head as one native node (~0.3 ms) only the top layer's images still fit there (16.98 vs 17.28 ms / step).
   if (layer_end == L && d[VL_ST_FIELDS + VL_LY_T_X]) {
     if (ss != (hipStream_t)stream) {
       VL_CHECK_ARG(fork, "vl_stack_fwd: a side stream needs the fork event of the descriptor");
@@ -163,22 +182,8 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
       if (e == hipSuccess) e = hipStreamWaitEvent(ss, fork, 0);
       if (e != hipSuccess) return vl_set_error(-3, "vl_stack_fwd: stream fork: %s", hipGetErrorString(e));
     }
-    for (int64_t l = L - 1; l >= 0; --l) {  // the order backward consumes them in
-      const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
-      const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;
-      const int64_t R = pooled ? B : M;
-      const int64_t tr[4 * VL_TR_FIELDS] = {
-          y[VL_LY_X_HI], H, H, y[VL_LY_T_X], 0, 0,
-          y[VL_LY_CTX_HI], H, H, y[VL_LY_T_CTX], 0, 0,
-          y[VL_LY_X1_HI], H, H, y[VL_LY_T_X1], 0, 0,
-          y[VL_LY_H_HI], I, I, y[VL_LY_T_H], 0, 0};
-      if (pooled) {
-        VL_TRY(vl_transpose_blocked(tr, 1, M, d[VL_ST_TR_BLOCKS_FWD], ss));
-        VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, d[VL_ST_TR_BLOCKS_FWD], ss));
-      } else {
-        VL_TRY(vl_transpose_blocked(tr, 4, M, d[VL_ST_TR_BLOCKS_FWD], ss));
-      }
-    }
+    for (int64_t l = L - 1; l >= d[VL_ST_TR_BWD_LAYERS] && l >= 0; --l)  // the order backward consumes them in
+      VL_TRY(x_images(d, l, d[VL_ST_TR_BLOCKS_FWD], ss));
   }
   return 0;
 }
@@ -245,6 +250,8 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
         y[VL_LY_DT2], H, H, d[VL_ST_T_DT2], 0, 0};
     VL_CHECK_ARG(y[VL_LY_T_X] && y[VL_LY_T_CTX] && y[VL_LY_T_X1] && y[VL_LY_T_H],
                  "vl_stack_bwd: the layer record lacks the K-major X images (forward ran without them)");
+    if (l < d[VL_ST_TR_BWD_LAYERS])  // not written at the end of forward
+      VL_TRY(x_images(d, l, d[VL_ST_TR_BLOCKS_BWD], ss));
     if (pooled) {  // dqkv has M rows, the other three only the B live ones
       VL_TRY(vl_transpose_blocked(tr, 1, M, d[VL_ST_TR_BLOCKS_BWD], ss));
       VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, d[VL_ST_TR_BLOCKS_BWD], ss));

@@ -248,6 +248,11 @@ class LayerStack(object):
         # live rows are bit-identical to the dense run, the dead ones are never computed)
         self.pooled_only = True
         self.tr_blocks = (0, 0)  # workgroup caps of the K-major re-layout launches (forward, backward); 0 = default
+        # K-major X images: the bottom `tr_bwd_layers` layers' are written in backward on the side stream, the others at
+        # the end of forward, in the window of the task head.  None = all but the top layer: since the head became one
+        # native node its window (~0.3 ms) no longer hides 12 layers of re-layout (0.78 ms); measured at c2, same box:
+        # 0 -> 17.28, 6 -> 17.11, 8 -> 17.04, 11 -> 16.98, 12 -> 17.02 ms / step
+        self.tr_bwd_layers = None
         self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
         # callable(layer) -> (16 destination views in LayerSpec.params order, accumulate) or None: when the optimizer
         # provides it, gradients are written straight into its flat arena
@@ -349,6 +354,7 @@ class LayerStack(object):
         d[VL["VL_ST_PROF"]] = 0 if self.prof is None else self.prof.ctypes.data
         d[VL["VL_ST_POOLED_ONLY"]] = 1 if self.pooled_only else 0
         d[VL["VL_ST_TR_BLOCKS_FWD"]], d[VL["VL_ST_TR_BLOCKS_BWD"]] = self.tr_blocks
+        d[VL["VL_ST_TR_BWD_LAYERS"]] = len(self.specs) - 1 if self.tr_bwd_layers is None else self.tr_bwd_layers
         side_ptr = None
         if ar.need_grad and self.overlap_dw:
             dev = ar.x32.device

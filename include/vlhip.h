@@ -206,7 +206,7 @@ int vl_ln_bwd_reduce2(const float* ws_a, int64_t M_a, float* dgamma_a, float* db
  * descending order: the critical path on stream_main, the optimizer-only work (K-major re-layout, column sums, grouped
  * weight-gradient GEMM) forked per layer onto stream_side (NULL = everything on stream_main); the caller joins them.
  * ------------------------------------------------------------------------------------------------------------ */
-#define VL_ST_MAGIC_VALUE 0x564c5354414b32ll
+#define VL_ST_MAGIC_VALUE 0x564c5354414b33ll
 enum {
   VL_ST_MAGIC = 0,
   VL_ST_B = 1,
@@ -240,7 +240,9 @@ enum {
   VL_ST_TR_BLOCKS_BWD = 29,
   VL_ST_SMALL_WS = 30, /* fp32 workspace of the small-M GEMM path (vl_gemm_nt_ex) for the B-row products of the pooled-row mode; 0 = none */
   VL_ST_SMALL_WS_FLOATS = 31,
-  VL_ST_FIELDS = 32
+  VL_ST_TR_BWD_LAYERS = 32, /* K-major X images: those of the bottom n layers are written in backward (side stream, ahead of the
+                               layer's own re-layout), the others at the end of forward (under the task head); 0 = all in forward */
+  VL_ST_FIELDS = 40
 };
 enum {
   VL_LY_X32 = 0,
