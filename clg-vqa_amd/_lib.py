@@ -19,8 +19,9 @@ _SIGS = {
     "vl_gemm_nt": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, P, P, P, c_int64,
                            P, P, P, c_int64, P]),
     "vl_gemm_nt_ex": (c_int, [P, P, c_int64, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int, P, P, P, c_int64,
-                              P, P, P, c_int64, c_int, P, c_int64, P]),
+                              P, P, P, c_int64, P, P]),
     "vl_gemm_small_ws_floats": (c_int64, [c_int64, c_int64, c_int64]),
+    "vl_gemm_nt_path": (c_int, [c_int64, c_int64, c_int64, c_int, c_int]),
     "vl_gemm_splitk_plan": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_splitk_ws_floats": (c_int64, [c_int64, c_int64, c_int64]),
     "vl_gemm_nt_splitk": (c_int, [P, c_int64, P, c_int64, c_int64, c_int64, c_int64, c_int64, P, P, P]),

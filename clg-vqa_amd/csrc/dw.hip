@@ -355,6 +355,9 @@ extern "C" int64_t vl_blocked_elems(int64_t M, int64_t N) { return ((M + 63) / 6
 
 // tab: HOST array of n x VL_TR_FIELDS int64 {src, ld, N, dst, colsum_partial (0 = none), 0}
 extern "C" int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, int64_t max_blocks, void* stream) {
+#ifdef VL_EXPERIMENT_SKIP_RELAYOUT  // timing experiment only (wrong results): what the step costs without the re-layout
+  if (M > 4096) return 0;
+#endif
   VL_CHECK_ARG(tab && n >= 1 && n <= MAXT && M >= 1 && M < (1LL << 31), "vl_transpose_blocked: bad arguments");
   TrArgs a{};
   a.n = (int)n; a.M = (int)M; a.mblocks = (int)((M + 63) / 64);

@@ -52,6 +52,11 @@ struct GemmArgs {
   int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
   int tile;                     // host-side kernel / tile selection (see above); not read by the kernels
   float* ws; long ws_floats;    // host-side: caller-owned workspace of the small-M path (may be NULL)
+  // 16-bit epilogues: additionally store out_hi in the K-major blocked layout of the weight-gradient GEMM
+  // (img[((m >> 6) * img_n + n) * 64 + (m & 63)], dw.hip) -- the producer writes the image, no re-layout pass reads the
+  // row-major copy back; cs (ping-pong kernel only): fp32 column sums of the rounded out_hi values per (tile, M half,
+  // wave row) -> cs[(tm * 2 + qm) * WR + wr][n], the bias-gradient partials the re-layout pass used to produce
+  bf16_raw* img; long img_n; float* cs;
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -61,10 +66,23 @@ __device__ __forceinline__ uint4 load_chunk(const bf16_raw* base, long ld, int r
   return make_uint4(0u, 0u, 0u, 0u);
 }
 
+// K-major image store of one row's consecutive columns: column n + t of row m lands 128 B after column n + t - 1; the 16
+// lanes that share lane >> 4 hold 16 consecutive rows of the same columns, i.e. one 32-byte segment per store and column
+template <int NV>
+__device__ __forceinline__ void image_store(const GemmArgs& p, int m, int n0, const bf16_raw* v) {
+  bf16_raw* dst = p.img + ((long)(m >> 6) * p.img_n + n0) * 64 + (m & 63);
+#pragma unroll
+  for (int t = 0; t < NV; ++t)
+    if (n0 + t < p.N) dst[t * 64] = v[t];
+}
+
 // Epilogue for 4 consecutive output columns n0..n0+3 of row m (the MFMA is issued as D^T = B.A^T so that a lane's
 // 4 accumulator registers are 4 consecutive n: 16-byte fp32 / 8-byte bf16 accesses instead of scalar ones).
+// want_cs: csum (4 accumulators of the caller) += the rounded out_hi values (column sums for the bias gradient); the
+// accumulators are passed by reference with constant indices only, so they stay in registers
 template <int EPI>
-__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32, int m, int n0, f32x4 v) {
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32, int m, int n0, f32x4 v, bool want_cs,
+                                                float (&csum)[4]) {
   const bool vec = p.vec && (n0 + 3 < p.N);
   if (vec) {
     if (p.bias) {
@@ -108,6 +126,14 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
         *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
         *reinterpret_cast<ushort4*>(p.out_lo + o) = lo;
       }
+      if (p.img || want_cs) {
+        const bf16_raw h4[4] = {hi.x, hi.y, hi.z, hi.w};
+        if (p.img) image_store<4>(p, m, n0, h4);
+        if (want_cs) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) csum[t] += bf16_to_f32(h4[t]);
+        }
+      }
     }
     return;
   }
@@ -116,6 +142,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
     const int n = n0 + r;
     if (n >= p.N) break;
     float x = v[r] + (p.bias ? p.bias[n] : 0.f);
+    bf16_raw hi = 0, lo = 0;
     if (EPI == VL_EPI_F32) {
       if (p.resid) x += p.resid[(long)m * p.ldc + n];
       out32[(long)m * p.ldc + n] = x;
@@ -123,22 +150,31 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
       float y, d;
       gelu_erf_both(x, y, d);
       p.aux16[(long)m * p.ld16 + n] = f32_to_bf16(d);
-      bf16_raw hi, lo;
       split_bf16(y, hi, lo);
       p.out_hi[(long)m * p.ld16 + n] = hi;
       p.out_lo[(long)m * p.ld16 + n] = lo;
     } else if (EPI == VL_EPI_DGELU_BF16) {
       const float u = bf16_to_f32(p.aux16[(long)m * p.ld16 + n]);
-      p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(x * u);
+      hi = f32_to_bf16(x * u);
+      p.out_hi[(long)m * p.ld16 + n] = hi;
     } else if (EPI == VL_EPI_BF16) {
-      p.out_hi[(long)m * p.ld16 + n] = f32_to_bf16(x);
+      hi = f32_to_bf16(x);
+      p.out_hi[(long)m * p.ld16 + n] = hi;
     } else {
-      bf16_raw hi, lo;
       split_bf16(x, hi, lo);
       p.out_hi[(long)m * p.ld16 + n] = hi;
       p.out_lo[(long)m * p.ld16 + n] = lo;
     }
+    if (EPI != VL_EPI_F32) {
+      if (p.img) p.img[((long)(m >> 6) * p.img_n + n) * 64 + (m & 63)] = hi;
+      if (want_cs) csum[r] += bf16_to_f32(hi);
+    }
   }
+}
+template <int EPI>
+__device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32, int m, int n0, f32x4 v) {
+  float unused[4] = {0.f, 0.f, 0.f, 0.f};
+  epilogue_store4<EPI>(p, out32, m, n0, v, false, unused);
 }
 
 // 8 consecutive output columns n0..n0+7 of row m (16-bit epilogues of the fast path: two paired MFMA tiles hold the two
@@ -148,10 +184,11 @@ __device__ __forceinline__ uint4 pack8(const ushort4& a, const ushort4& b) {
                     (unsigned)b.x | ((unsigned)b.y << 16), (unsigned)b.z | ((unsigned)b.w << 16));
 }
 template <int EPI>
-__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32, int m, int n0, f32x4 v0, f32x4 v1) {
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32, int m, int n0, f32x4 v0, f32x4 v1,
+                                                bool want_cs, float (&c0)[4], float (&c1)[4]) {
   if (!(p.vec8 && n0 + 7 < p.N)) {
-    epilogue_store4<EPI>(p, out32, m, n0, v0);
-    if (n0 + 4 < p.N) epilogue_store4<EPI>(p, out32, m, n0 + 4, v1);
+    epilogue_store4<EPI>(p, out32, m, n0, v0, want_cs, c0);
+    if (n0 + 4 < p.N) epilogue_store4<EPI>(p, out32, m, n0 + 4, v1, want_cs, c1);
     return;
   }
   float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -197,6 +234,19 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32,
     *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
     *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
   }
+  if (p.img || want_cs) {
+    const bf16_raw h8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    if (p.img) image_store<8>(p, m, n0, h8);
+    if (want_cs) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { c0[t] += bf16_to_f32(h8[t]); c1[t] += bf16_to_f32(h8[4 + t]); }
+    }
+  }
+}
+template <int EPI>
+__device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32, int m, int n0, f32x4 v0, f32x4 v1) {
+  float u0[4] = {0.f, 0.f, 0.f, 0.f}, u1[4] = {0.f, 0.f, 0.f, 0.f};
+  epilogue_store8<EPI>(p, out32, m, n0, v0, v1, false, u0, u1);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -576,8 +626,18 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 
   // epilogue.  D^T layout: lane&15 -> m inside the 16-row tile, 4*(lane>>4) + reg -> n inside the 16-col tile
   float* out32 = p.out32;
+  // (column sums are wired for the GELU' epilogue only -- the one product whose bias gradient needs them; the erf-GELU
+  // epilogue on the 256 x 256 tile has no registers to spare for 16 more accumulators)
+  const bool want_cs = EPI == VL_EPI_DGELU_BF16 && p.cs != nullptr;
 #pragma unroll
-  for (int qm = 0; qm < 2; ++qm)
+  for (int qm = 0; qm < 2; ++qm) {
+    float csum[2][NJ][4];  // column sums of the rounded out_hi values over this wave's rows of the M half
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) csum[qn][j][t] = 0.f;
 #pragma unroll
     for (int i = 0; i < (qm == 0 ? MI : MI1); ++i) {
       const int m = row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane & 15);
@@ -590,13 +650,39 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
           if (j < NJP) {
             if (j & 1) continue;
             const int n0 = cb + 32 * (j >> 1) + 8 * (lane >> 4);
-            if (n0 < p.N) epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j]);
+            if (n0 < p.N)
+              epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j], want_cs,
+                                   csum[qn][j], csum[qn][j + 1 < NJ ? j + 1 : j]);
           } else {
             const int n0 = cb + j * 16 + 4 * (lane >> 4);
-            if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j]);
+            if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j], want_cs, csum[qn][j]);
           }
         }
     }
+    if (EPI == VL_EPI_DGELU_BF16 && want_cs) {  // one partial row per (tile row, M half, wave row): sum over the 16 row lanes, then store
+      float* dst = p.cs + (long)((tm * 2 + qm) * WR + wr) * p.N;
+#pragma unroll
+      for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          float v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float x = csum[qn][j][t];
+            x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
+            v[t] = x;
+          }
+          if ((lane & 15) == 0) {
+            const int cb = col0 + qn * BH + wc * (NJ * 16);
+            // paired tiles (j, j+1): csum[j] = columns +0..3, csum[j+1] = columns +4..7 of the lane's 8-column group
+            const int n0 = j < NJP ? cb + 32 * (j >> 1) + 8 * (lane >> 4) + 4 * (j & 1) : cb + j * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (n0 + t < p.N) dst[n0 + t] = v[t];
+          }
+        }
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1028,6 +1114,7 @@ int launch2w(GemmArgs a, hipStream_t stream, int splits) {
   VL_CHECK_LAUNCH("vl_gemm_nt(fast)");
   return 0;
 }
+thread_local int tl_cs_rows = 0;  // scratch of one vl_gemm_nt_ex call (reported through VL_GX_COLSUM_ROWS)
 template <int NSPLIT, int EPI, int CFG>
 int launch3(GemmArgs a, hipStream_t stream) {
   constexpr int BMT = CFG == 2 ? 224 : 256, BNT = CFG == 1 ? 192 : 256;
@@ -1041,6 +1128,7 @@ int launch3(GemmArgs a, hipStream_t stream) {
   }
   a.tiles_m = (a.M + BMT - 1) / BMT;
   a.tiles_n = (a.N + BNT - 1) / BNT;
+  tl_cs_rows = a.tiles_m * 2 * (CFG == 1 ? 4 : 2);  // column-sum partial rows this configuration writes
   hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt(ping-pong)");
   return 0;
@@ -1074,7 +1162,7 @@ inline bool fast_ok(int64_t M, int64_t K, int64_t k_len, int passes, int tile) {
 
 template <int NSPLIT, int EPI>
 int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
-  if (splits == 1 && a.ws && (a.tile == 8 || (a.tile == 0 && small_shape(a.M, a.N)))) {
+  if (splits == 1 && a.ws && !a.cs && (a.tile == 8 || (a.tile == 0 && small_shape(a.M, a.N)))) {
     const SmallPlan pl = small_plan(a.M, a.N, a.K);
     if ((long)pl.splits * a.M * pl.ldw <= a.ws_floats) return launch_small<NSPLIT, EPI>(a, a.ws, s);
     if (a.tile == 8) return vl_set_error(-1, "vl_gemm_nt_ex: workspace too small for the small-M path");
@@ -1095,6 +1183,7 @@ int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
     }
     return wide ? launch3<NSPLIT, EPI, 0>(a, s) : launch3<NSPLIT, EPI, 1>(a, s);
   }
+  if (a.cs) return vl_set_error(-2, "vl_gemm_nt_ex: column sums are produced by the ping-pong kernel only (see vl_gemm_nt_path)");
   if (fast_ok(a.M, a.K, a.k_len, NSPLIT, a.tile)) {
     switch (pick_bn(a.M, a.N, splits, a.tile)) {
       case 256: return launch2<NSPLIT, EPI, 256>(a, s, splits);
@@ -1121,20 +1210,31 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+// which kernel the automatic choice takes: 0 generic | 1 single-barrier | 2 ping-pong | 3 small-M (needs a workspace)
+extern "C" int vl_gemm_nt_path(int64_t M, int64_t N, int64_t K, int passes, int has_ws) {
+  if (has_ws && small_shape(M, N)) return 3;
+  if (M >= 256 && N >= 192 && (K % (passes == 3 ? 32 : 64)) == 0) return 2;
+  if (fast_ok(M, K, K, passes, 0)) return 1;
+  return 0;
+}
+
 extern "C" int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                           int64_t ldb, int64_t M, int64_t N, int64_t K, int passes, int epilogue,
                           const float* bias, const float* resid32, float* out32, int64_t ldc, void* out_hi,
                           void* out_lo, void* aux16, int64_t ld16, void* stream) {
   return vl_gemm_nt_ex(a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, passes, epilogue, bias, resid32, out32, ldc, out_hi, out_lo,
-                       aux16, ld16, 0, nullptr, 0, stream);
+                       aux16, ld16, nullptr, stream);
 }
 
-// ... with an explicit kernel / tile selection (tests and micro-benchmarks; 0 = the automatic choice of vl_gemm_nt)
+// ... with the optional arguments of `extra` (HOST array of VL_GX_FIELDS int64, may be NULL): kernel / tile selection,
+// small-M workspace, K-major image of out_hi, column-sum partials
 extern "C" int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo,
                              int64_t ldb, int64_t M, int64_t N, int64_t K, int passes, int epilogue,
                              const float* bias, const float* resid32, float* out32, int64_t ldc, void* out_hi,
-                             void* out_lo, void* aux16, int64_t ld16, int tile, float* ws, int64_t ws_floats,
-                             void* stream) {
+                             void* out_lo, void* aux16, int64_t ld16, int64_t* extra, void* stream) {
+  const int tile = extra ? (int)extra[VL_GX_TILE] : 0;
+  float* ws = extra ? reinterpret_cast<float*>(static_cast<uintptr_t>(extra[VL_GX_WS])) : nullptr;
+  const int64_t ws_floats = extra ? extra[VL_GX_WS_FLOATS] : 0;
   VL_CHECK_ARG(passes == 1 || passes == 3, "vl_gemm_nt: passes must be 1 or 3 (got %d)", passes);
   VL_CHECK_ARG(tile == 0 || (tile >= 2 && tile <= 8) || tile == 128 || tile == 192 || tile == 256,
                "vl_gemm_nt_ex: unknown tile selection %d", tile);
@@ -1167,12 +1267,23 @@ extern "C" int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, co
   VL_CHECK_ARG(tile != 8 || ws, "vl_gemm_nt_ex: tile 8 (small-M path) needs a workspace");
   VL_CHECK_ARG(!ws || ((reinterpret_cast<uintptr_t>(ws) & 15u) == 0 && ws_floats >= 0), "vl_gemm_nt_ex: workspace must be 16-byte aligned");
   a.ws = ws; a.ws_floats = ws_floats;
+  if (extra && (extra[VL_GX_IMG] || extra[VL_GX_COLSUM])) {
+    VL_CHECK_ARG(epilogue != VL_EPI_F32, "vl_gemm_nt_ex: the K-major image / column sums belong to the 16-bit epilogues");
+    a.img = reinterpret_cast<bf16_raw*>(static_cast<uintptr_t>(extra[VL_GX_IMG]));
+    a.img_n = extra[VL_GX_IMG_COLS];
+    a.cs = reinterpret_cast<float*>(static_cast<uintptr_t>(extra[VL_GX_COLSUM]));
+    VL_CHECK_ARG(!a.img || a.img_n >= N, "vl_gemm_nt_ex: the image needs VL_GX_IMG_COLS >= N");
+    VL_CHECK_ARG(!a.cs || epilogue == VL_EPI_DGELU_BF16, "vl_gemm_nt_ex: column sums are wired for the DGELU epilogue");
+  }
+  tl_cs_rows = 0;
   a.vec8 = (ld16 & 7) == 0 && aligned16(bias) && aligned16(out_hi) && aligned16(out_lo) && aligned16(aux16);
   a.vec = ((ldc | ld16) & 3) == 0 && aligned16(bias) && aligned16(resid32) && aligned16(out32) &&
           ((reinterpret_cast<uintptr_t>(out_hi) | reinterpret_cast<uintptr_t>(out_lo) |
             reinterpret_cast<uintptr_t>(aux16)) & 7) == 0;
   hipStream_t s = (hipStream_t)stream;
-  return passes == 3 ? dispatch_epi<3>(epilogue, a, s) : dispatch_epi<1>(epilogue, a, s);
+  const int rc = passes == 3 ? dispatch_epi<3>(epilogue, a, s) : dispatch_epi<1>(epilogue, a, s);
+  if (extra) extra[VL_GX_COLSUM_ROWS] = a.cs ? tl_cs_rows : 0;
+  return rc;
 }
 
 // floats of workspace the small-M path wants for this shape (0: the shape never takes it)

@@ -51,14 +51,34 @@ void prof_end(int64_t* pair, int64_t tag, int64_t flops, void* stream) {
 // vl_gemm_nt, optionally bracketed by a caller-owned event pair (descriptor field VL_ST_PROF); B-row products of the
 // pooled-row mode take the small-M path through the descriptor's workspace (VL_ST_SMALL_WS)
 struct GemmCtx { int64_t* prof; float* ws; int64_t ws_floats; };
+struct GemmImage { void* img; int64_t cols; float* colsum; int64_t* colsum_rows; };
 int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
          int64_t M, int64_t N, int64_t K, int passes, int epi, const float* bias, const float* resid, float* out32,
-         int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream) {
+         int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream, const GemmImage* im = nullptr) {
   int64_t* pair = prof_begin(g.prof, stream);
+  int64_t extra[VL_GX_FIELDS] = {0};
+  extra[VL_GX_WS] = (int64_t)(uintptr_t)g.ws; extra[VL_GX_WS_FLOATS] = g.ws_floats;
+  if (im) {
+    extra[VL_GX_IMG] = (int64_t)(uintptr_t)im->img; extra[VL_GX_IMG_COLS] = im->cols;
+    extra[VL_GX_COLSUM] = (int64_t)(uintptr_t)im->colsum;
+    if (im->colsum) extra[VL_GX_WS] = extra[VL_GX_WS_FLOATS] = 0;
+  }
   const int rc = vl_gemm_nt_ex(a_hi, a_lo, lda, b_hi, b_lo, ldb, M, N, K, passes, epi, bias, resid, out32, ldc, out_hi, out_lo,
-                               aux16, ld16, 0, g.ws, g.ws_floats, stream);
+                               aux16, ld16, extra, stream);
+  if (im && im->colsum_rows) *im->colsum_rows = extra[VL_GX_COLSUM_ROWS];
   prof_end(pair, passes * 16 + epi, 2 * M * N * K, stream);
   return rc;
+}
+
+// The two [M, I] operands of the weight-gradient GEMMs -- GELU output h (X side of dW2) and du (dY side of dW1, + the
+// column sums that are b1's gradient) -- are written as K-major images by the epilogues of the GEMMs that produce them
+// when those run on the ping-pong kernel over whole 64-row blocks: half of the re-layout traffic never happens.
+bool fused_images(const int64_t* d, int64_t l) {
+  const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I], L = d[VL_ST_NLAYERS], M = B * S;
+  const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;
+  const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
+  return !pooled && M % 64 == 0 && y[VL_LY_T_H] && y[VL_LY_T_DU] && y[VL_LY_CS_DU] &&
+         vl_gemm_nt_path(M, I, H, 1, d[VL_ST_SMALL_WS] != 0) == 2;
 }
 
 int check_header(const char* fn, const int64_t* d) {
@@ -85,7 +105,7 @@ int x_images(const int64_t* d, int64_t l, int64_t max_blocks, hipStream_t ss) {
     VL_TRY(vl_transpose_blocked(tr, 1, M, max_blocks, ss));
     return vl_transpose_blocked(tr + VL_TR_FIELDS, 3, B, max_blocks, ss);
   }
-  return vl_transpose_blocked(tr, 4, M, max_blocks, ss);
+  return vl_transpose_blocked(tr, fused_images(d, l) ? 3 : 4, M, max_blocks, ss);  // (h: by the FFN1 epilogue)
 }
 
 }  // namespace
@@ -157,9 +177,10 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
                      ptr<const float>(y[VL_LY_LN1_G]), ptr<const float>(y[VL_LY_LN1_B]), eps, ptr<float>(y[VL_LY_X1_32]),
                      ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), ptr<float>(y[VL_LY_MEAN1]), ptr<float>(y[VL_LY_RSTD1]),
                      R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 1), os, os, stream));
+    const GemmImage him{ptr<void>(y[VL_LY_T_H]), I, nullptr, nullptr};
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), H, ptr<void>(y[VL_LY_W1_HI]), ptr<void>(y[VL_LY_W1_LO]), H,
                 R, I, H, 3, VL_EPI_GELU_SPLIT, ptr<const float>(y[VL_LY_B1]), nullptr, nullptr, 0, ptr<void>(y[VL_LY_H_HI]),
-                ptr<void>(y[VL_LY_H_LO]), ptr<void>(y[VL_LY_U16]), I, stream));
+                ptr<void>(y[VL_LY_H_LO]), ptr<void>(y[VL_LY_U16]), I, stream, fused_images(d, l) ? &him : nullptr));
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_H_HI]), ptr<void>(y[VL_LY_H_LO]), I, ptr<void>(y[VL_LY_W2_HI]), ptr<void>(y[VL_LY_W2_LO]), I,
                 R, H, I, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_B2]), nullptr, ptr<float>(y[VL_LY_Z2]), H, nullptr, nullptr,
                 nullptr, 0, stream));
@@ -216,8 +237,12 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
                      ptr<const float>(y[VL_LY_RSTD2]), ptr<const float>(y[VL_LY_LN2_G]), nullptr, row_post, ptr<float>(y[VL_LY_DZ2]),
                      ptr<void>(y[VL_LY_DT2]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS2]), R, H, R, 0, 0, p_hid, 0.f,
                      seed_of(d[VL_ST_SEED0], s3 + 2), os, sm));
+    const bool fused = fused_images(d, l);
+    int64_t cs_du_rows = 0;
+    const GemmImage duim{ptr<void>(y[VL_LY_T_DU]), I, ptr<float>(y[VL_LY_CS_DU]), &cs_du_rows};
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_DT2]), nullptr, H, ptr<void>(y[VL_LY_W2_T]), nullptr, H, R, I, H, 1, VL_EPI_DGELU_BF16,
-                nullptr, nullptr, nullptr, 0, ptr<void>(y[VL_LY_DU16]), nullptr, ptr<void>(y[VL_LY_U16]), I, sm));
+                nullptr, nullptr, nullptr, 0, ptr<void>(y[VL_LY_DU16]), nullptr, ptr<void>(y[VL_LY_U16]), I, sm,
+                fused ? &duim : nullptr));
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_DU16]), nullptr, I, ptr<void>(y[VL_LY_W1_T]), nullptr, I, R, H, I, 1, VL_EPI_F32, nullptr,
                 ptr<const float>(y[VL_LY_DZ2]), ptr<float>(y[VL_LY_DX1]), H, nullptr, nullptr, nullptr, 0, sm));
     VL_TRY(vl_ln_bwd(ptr<const float>(y[VL_LY_DX1]), ptr<const float>(y[VL_LY_Z1]), ptr<const float>(y[VL_LY_MEAN1]),
@@ -246,8 +271,8 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
     const int64_t tr[4 * VL_TR_FIELDS] = {
         y[VL_LY_DQKV], 3 * H, 3 * H, d[VL_ST_T_DQKV], d[VL_ST_CS_QKV], 0,
         y[VL_LY_DT1], H, H, d[VL_ST_T_DT1], 0, 0,
-        y[VL_LY_DU16], I, I, d[VL_ST_T_DU], d[VL_ST_CS_U], 0,
-        y[VL_LY_DT2], H, H, d[VL_ST_T_DT2], 0, 0};
+        y[VL_LY_DT2], H, H, d[VL_ST_T_DT2], 0, 0,
+        y[VL_LY_DU16], I, I, d[VL_ST_T_DU], d[VL_ST_CS_U], 0};  // (last: written by the GELU' epilogue when `fused`)
     VL_CHECK_ARG(y[VL_LY_T_X] && y[VL_LY_T_CTX] && y[VL_LY_T_X1] && y[VL_LY_T_H],
                  "vl_stack_bwd: the layer record lacks the K-major X images (forward ran without them)");
     if (l < d[VL_ST_TR_BWD_LAYERS])  // not written at the end of forward
@@ -256,7 +281,7 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
       VL_TRY(vl_transpose_blocked(tr, 1, M, d[VL_ST_TR_BLOCKS_BWD], ss));
       VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, d[VL_ST_TR_BLOCKS_BWD], ss));
     } else {
-      VL_TRY(vl_transpose_blocked(tr, 4, M, d[VL_ST_TR_BLOCKS_BWD], ss));
+      VL_TRY(vl_transpose_blocked(tr, fused ? 3 : 4, M, d[VL_ST_TR_BLOCKS_BWD], ss));
     }
     // one launch: LayerNorm partials -> (dgamma, dbeta, bias gradient of the producing Linear) x 2, column-sum partials
     // of dqkv -> (bq, bk, bv) and of du -> b1
@@ -265,14 +290,14 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
         y[VL_LY_LNWS2], nws, 3 * H, H, y[VL_LY_GRAD0 + 14], y[VL_LY_GRAD0 + 15], y[VL_LY_GRAD0 + 13], 0,
         y[VL_LY_LNWS1], nws, 3 * H, H, y[VL_LY_GRAD0 + 8], y[VL_LY_GRAD0 + 9], y[VL_LY_GRAD0 + 7], 0,
         d[VL_ST_CS_QKV], mblk, 3 * H, H, y[VL_LY_GRAD0 + 1], y[VL_LY_GRAD0 + 3], y[VL_LY_GRAD0 + 5], 0,
-        d[VL_ST_CS_U], rblk, I, I, y[VL_LY_GRAD0 + 11], 0, 0, 0};
+        fused ? y[VL_LY_CS_DU] : d[VL_ST_CS_U], fused ? cs_du_rows : rblk, I, I, y[VL_LY_GRAD0 + 11], 0, 0, 0};
     VL_TRY(vl_colreduce_multi(cr, 4, accumulate, ss));
     const int64_t pr[6 * VL_DW_FIELDS] = {
         d[VL_ST_T_DQKV], 3 * H, y[VL_LY_T_X], H, y[VL_LY_GRAD0 + 0], H, y[VL_LY_MASK0 + 0], H, H, 0,
         d[VL_ST_T_DQKV] + 2 * 64 * H, 3 * H, y[VL_LY_T_X], H, y[VL_LY_GRAD0 + 2], H, y[VL_LY_MASK0 + 1], H, H, 0,
         d[VL_ST_T_DQKV] + 2 * 64 * 2 * H, 3 * H, y[VL_LY_T_X], H, y[VL_LY_GRAD0 + 4], H, y[VL_LY_MASK0 + 2], H, H, 0,
         d[VL_ST_T_DT1], H, y[VL_LY_T_CTX], H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
-        d[VL_ST_T_DU], I, y[VL_LY_T_X1], H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, 0,
+        fused ? y[VL_LY_T_DU] : d[VL_ST_T_DU], I, y[VL_LY_T_X1], H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, 0,
         d[VL_ST_T_DT2], H, y[VL_LY_T_H], I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
     if (pooled) {  // Q/K/V gradients reduce over all M rows, the other three over the B live rows
       VL_TRY(vl_dw_grouped(pr, 3, M, accumulate, ss));

@@ -226,6 +226,9 @@ class StackArena(object):
             # K-major images of the X operands: per layer, written during forward on the side stream
             nx, ni = lib.vl_blocked_elems(M, H), lib.vl_blocked_elems(M, I)
             self.t_x, self.t_ctx, self.t_x1, self.t_h = b16(L, nx), b16(L, nx), b16(L, nx), b16(L, ni)
+            # du's image + its column-sum partials per layer: written by the GELU' epilogue on the main stream while the
+            # side stream may still be reading the layer above's
+            self.t_du_l, self.cs_du_l = b16(L, ni), f32(L, 4 * ((M + 223) // 224), I)
             mb = (M + 63) // 64
             self.cs_qkv, self.cs_u = f32(mb, 3 * H), f32(mb, I)
             self.fork = torch.cuda.Event()
@@ -247,6 +250,7 @@ class LayerStack(object):
         # last layer then runs on the B live rows after its K/V projection and the stack returns [B, 1, H] (exact: the
         # live rows are bit-identical to the dense run, the dead ones are never computed)
         self.pooled_only = True
+        self.fuse_images = True  # h / du K-major images written by the GEMM epilogues (A/B knob; False = re-layout pass)
         self.tr_blocks = (0, 0)  # workgroup caps of the K-major re-layout launches (forward, backward); 0 = default
         # K-major X images: the bottom `tr_bwd_layers` layers' are written in backward on the side stream, the others at
         # the end of forward, in the window of the task head.  None = all but the top layer: since the head became one
@@ -338,6 +342,8 @@ class LayerStack(object):
                 put("DZ2", ar.dz2); put("DX1", ar.dx1); put("DZ1", ar.dz1); put("DCTX16", ar.dctx16)
                 for name in ("dt2", "du16", "dt1", "dqkv", "lnws1", "lnws2", "t_x", "t_ctx", "t_x1", "t_h"):
                     put(name.upper(), getattr(ar, name)[l])
+                if self.fuse_images:
+                    put("T_DU", ar.t_du_l[l]); put("CS_DU", ar.cs_du_l[l])
         self._desc[id(ar)] = (fp, d)
         return d
 

@@ -76,9 +76,12 @@ def small_ws(device, floats, stream):
 
 
 def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=None, out32=None, out_hi=None,
-            out_lo=None, aux16=None, tile=0):
+            out_lo=None, aux16=None, tile=0, image=None, image_cols=0, colsum=None):
     """C[M,N] = A[M,K] . B[N,K]^T (+epilogue); operands are bf16 2-D tensors (row-major, ld = stride(0)).  Products
-    with a small M (the batch-sized products of the head) get a workspace and take the library's small-M path."""
+    with a small M (the batch-sized products of the head) get a workspace and take the library's small-M path.
+    image / image_cols: also store out_hi as the K-major image of the weight-gradient GEMM; colsum [rows, N] fp32:
+    column-sum partials of out_hi (DGELU epilogue, ping-pong kernel) -- returns the number of partial rows written."""
+    import ctypes
     pa, lda = _pld(a_hi)
     pb, ldb = _pld(b_hi)
     pal = _pld(a_lo)[0] if a_lo is not None else None
@@ -91,13 +94,21 @@ def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=
         assert resid.stride(0) == ldc
     L = _lib.lib()
     tile = tile or GEMM_TILE
-    ws, nws, st = None, 0, _stream()
-    if M <= 8192 and tile in (0, 8) and (SMALL_GEMM or tile == 8):
+    st = _stream()
+    extra = (ctypes.c_int64 * 8)()
+    extra[0] = tile
+    if M <= 8192 and tile in (0, 8) and colsum is None and (SMALL_GEMM or tile == 8):
         nws = L.vl_gemm_small_ws_floats(M, N, K)
-        ws = small_ws(a_hi.device, nws, st).data_ptr()
+        extra[1], extra[2] = small_ws(a_hi.device, nws, st).data_ptr(), nws
+    if image is not None:
+        extra[3], extra[4] = _p(image), image_cols or N
+    if colsum is not None:
+        assert colsum.shape[1] == N
+        extra[5] = _p(colsum)
     _lib.check(L.vl_gemm_nt_ex(pa, pal, lda, pb, pbl, ldb, M, N, K, passes, epilogue, _p(bias),
                                _pld(resid)[0] if resid is not None else None, po32, ldc, ph, pl, px, ld16,
-                               tile, ws, nws, st), "vl_gemm_nt")
+                               ctypes.cast(extra, ctypes.c_void_p), st), "vl_gemm_nt")
+    return int(extra[6])
 
 
 def gemm_nt_splitk(a_hi, b_hi, M, N, K, out32, splits=None):

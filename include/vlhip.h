@@ -48,19 +48,32 @@ enum {
 int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
                int64_t M, int64_t N, int64_t K, int passes, int epilogue, const float* bias, const float* resid32,
                float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, void* stream);
-/* The same with an explicit kernel / tile selection (tests, micro-benchmarks; the library keeps no tuning state):
- * tile = 0 automatic (what vl_gemm_nt does) | 2 / 3 / 5 eight-wave ping-pong kernel with 256x256 / 256x192 / 224x256 tiles |
- * 4 ping-pong, width by cost model only | 6 single-barrier kernel | 7 generic 128x128 kernel | 128 / 192 / 256
- * single-barrier kernel of that width | 8 small-M path.
- * ws / ws_floats (may be NULL / 0): caller-owned fp32 workspace of the SMALL-M PATH -- products whose M is the batch (the
- * pooled rows of the last layer, pooler, classifier: encoders.py:597-608, :788-815) would run on 4-16 of the 256 CUs
- * with the big tiles, bound by memory latency; with a workspace of >= vl_gemm_small_ws_floats(M, N, K) floats they run
- * as 64x64 tiles x K ranges (~500 workgroups, raw partial tiles into the workspace) + one launch that sums the ranges
- * in a fixed order and applies the epilogue.  Automatic (tile 0) when fewer than 100 big tiles would be launched. */
+/* The same with optional arguments in `extra`, a HOST array of VL_GX_FIELDS int64 (NULL = none; the library keeps no
+ * tuning state):
+ *  VL_GX_TILE  0 automatic (what vl_gemm_nt does) | 2 / 3 / 5 eight-wave ping-pong kernel with 256x256 / 256x192 / 224x256
+ *              tiles | 4 ping-pong, width by cost model only | 6 single-barrier kernel | 7 generic 128x128 kernel |
+ *              128 / 192 / 256 single-barrier kernel of that width | 8 small-M path.
+ *  VL_GX_WS / VL_GX_WS_FLOATS  caller-owned fp32 workspace of the SMALL-M PATH -- products whose M is the batch (the pooled
+ *              rows of the last layer, pooler, classifier: encoders.py:597-608, :788-815) would run on 4-16 of the 256 CUs
+ *              with the big tiles, bound by memory latency; with >= vl_gemm_small_ws_floats(M, N, K) floats they run as
+ *              64x64 tiles x K ranges (~500 workgroups, raw partial tiles into the workspace) + one launch that sums the
+ *              ranges in a fixed order and applies the epilogue.  Automatic (tile 0) below 100 big tiles.
+ *  VL_GX_IMG / VL_GX_IMG_COLS  (16-bit epilogues) additionally store out_hi as the K-MAJOR IMAGE the weight-gradient GEMM
+ *              reads (vl_transpose_blocked's layout: img[((m >> 6) * IMG_COLS + n) * 64 + (m & 63)]): the producer writes
+ *              it, no re-layout pass re-reads the row-major copy.  Rows [M, ceil64(M)) of the image are NOT written: use it
+ *              when M is a multiple of 64, or zero them.
+ *  VL_GX_COLSUM  (DGELU epilogue, ping-pong kernel only -- vl_gemm_nt_path() == 2) fp32 [rows, N] partial column sums of
+ *              the rounded out_hi values, the bias-gradient partials the re-layout pass used to produce; on return
+ *              VL_GX_COLSUM_ROWS holds the number of partial rows written (<= 4 * ceil(M / 224)): sum them with
+ *              vl_colreduce_multi. */
+enum { VL_GX_TILE = 0, VL_GX_WS = 1, VL_GX_WS_FLOATS = 2, VL_GX_IMG = 3, VL_GX_IMG_COLS = 4, VL_GX_COLSUM = 5,
+       VL_GX_COLSUM_ROWS = 6, VL_GX_FIELDS = 8 };
 int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
                   int64_t M, int64_t N, int64_t K, int passes, int epilogue, const float* bias, const float* resid32,
-                  float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, int tile,
-                  float* ws, int64_t ws_floats, void* stream);
+                  float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, int64_t* extra,
+                  void* stream);
+/* the kernel the automatic choice takes for a shape: 0 generic | 1 single-barrier | 2 ping-pong | 3 small-M */
+int vl_gemm_nt_path(int64_t M, int64_t N, int64_t K, int passes, int has_ws);
 int64_t vl_gemm_small_ws_floats(int64_t M, int64_t N, int64_t K);
 
 /* Split-K form for the weight gradients dW[M,N] = A[M,K] * B[N,K]^T with K = B*S rows (bf16 single pass, fp32 out,
@@ -306,6 +319,10 @@ enum {
   VL_LY_T_CTX = 78,
   VL_LY_T_X1 = 79,
   VL_LY_T_H = 80,
+  VL_LY_T_DU = 81, /* per-layer K-major image of du16 + its column-sum partials [4 * ceil(M / 224), I]: written by the GELU'
+                      epilogue of the FFN1-backward GEMM on the MAIN stream while the side stream may still read the layer
+                      above's (0 = use the shared VL_ST_T_DU / VL_ST_CS_U through the re-layout pass) */
+  VL_LY_CS_DU = 82,
   VL_LY_FIELDS = 96
 };
 /* Pooled-row mode (VL_ST_POOLED_ONLY): the head reads hidden_states[:, 0] only (BertTextPooler, encoders.py:597-608; M3P

@@ -868,3 +868,40 @@ def test_head_activation_kernels(M, N):
             ops.act_bwd(dy, None if act == ops.ACT_NONE else z, M, N, act, p, seed, dz32=dz32, dz16=dz16)
             torch.testing.assert_close(dz32, zz.grad, rtol=1e-5, atol=2e-6)
             assert torch.equal(dz16[:, :N], dz32.to(BF16)) and (dz16[:, N:].float() == 0).all()
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(1024, 3072, 768, 0), (896, 3072, 768, 5), (512, 768, 256, 3), (640, 1024, 128, 2)])
+def test_gemm_epilogue_writes_the_kmajor_image_and_column_sums(M, N, K, tile):
+    """VL_GX_IMG / VL_GX_COLSUM: the 16-bit epilogues store out_hi additionally as the K-major image of the weight-gradient
+    GEMM (bit-equal to vl_transpose_blocked of the row-major out_hi) and, for the GELU' epilogue, the column-sum partials
+    whose total is the bias gradient."""
+    from clg_vqa_amd import _lib
+    L = _lib.lib()
+    x, w = _rand(M, K, seed=70), _rand(N, K, seed=71, scale=0.05)
+    bias = _rand(N, seed=72)
+    a, al = _split(x)
+    b, bl = _split(w)
+    img_ref = torch.empty(L.vl_blocked_elems(M, N), dtype=BF16, device=DEV)
+    # forward: erf-GELU + split
+    hi, lo, aux = (torch.empty(M, N, dtype=BF16, device=DEV) for _ in range(3))
+    img = torch.full((L.vl_blocked_elems(M, N),), float("nan"), dtype=BF16, device=DEV)
+    ops.gemm_nt(a, al, b, bl, M, N, K, 3, EPI_GELU_SPLIT, bias=bias, out_hi=hi, out_lo=lo, aux16=aux, tile=tile, image=img)
+    ops.transpose_blocked([(hi, img_ref, None)], M)
+    assert torch.equal(img.view(torch.int16), img_ref.view(torch.int16))
+    hi0 = torch.empty_like(hi)
+    ops.gemm_nt(a, al, b, bl, M, N, K, 3, EPI_GELU_SPLIT, bias=bias, out_hi=hi0, out_lo=lo, aux16=aux, tile=tile)
+    assert torch.equal(hi, hi0)  # the row-major outputs do not change
+    # backward: GELU' multiply + bf16, image + column sums
+    du = torch.empty(M, N, dtype=BF16, device=DEV)
+    cs = torch.full((4 * ((M + 223) // 224), N), float("nan"), device=DEV)
+    img.fill_(float("nan"))
+    rows = ops.gemm_nt(a, None, b, None, M, N, K, 1, EPI_DGELU_BF16, out_hi=du, aux16=aux, tile=tile, image=img, colsum=cs)
+    assert 0 < rows <= cs.shape[0]
+    ops.transpose_blocked([(du, img_ref, None)], M)
+    assert torch.equal(img.view(torch.int16), img_ref.view(torch.int16))
+    ref = du.double().sum(0)
+    got = cs[:rows].double().sum(0)
+    assert (got - ref).abs().max().item() <= 1e-5 * du.double().abs().sum(0).max().item() + 1e-6
+    out = torch.empty(N, device=DEV)
+    ops.colreduce_multi([(cs[:rows], N, (out,))])
+    torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-4)

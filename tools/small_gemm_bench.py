@@ -24,11 +24,16 @@ def run(M, N, K, passes, tile, ws):
     filler = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
     st = torch.cuda.current_stream().cuda_stream
 
+    import ctypes
+    extra = (ctypes.c_int64 * 8)()
+    extra[0] = tile
+    if ws is not None:
+        extra[1], extra[2] = ws.data_ptr(), ws.numel()
+
     def call():
         _lib.check(L.vl_gemm_nt_ex(xh.data_ptr(), xl.data_ptr() if passes == 3 else None, K, wh.data_ptr(),
                                    wl.data_ptr() if passes == 3 else None, K, M, N, K, passes, EPI_F32, None, None,
-                                   out.data_ptr(), N, None, None, None, 0, tile, ws.data_ptr() if ws is not None else None,
-                                   ws.numel() if ws is not None else 0, st), "gemm")
+                                   out.data_ptr(), N, None, None, None, 0, ctypes.cast(extra, ctypes.c_void_p), st), "gemm")
     for _ in range(3):
         call()
     ts = []
