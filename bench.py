@@ -238,8 +238,8 @@ def main():
             masked_elems += w.numel()
     if os.environ.get("BENCH_TR_BLOCKS"):  # A/B: workgroup caps of the K-major re-layout launches, "fwd,bwd"
         model.engine.stack.tr_blocks = tuple(int(x) for x in os.environ["BENCH_TR_BLOCKS"].split(","))
-    if os.environ.get("BENCH_NO_FUSED_IMAGES", "0") == "1":  # A/B: h / du K-major images by the re-layout pass
-        model.engine.stack.fuse_images = False
+    if os.environ.get("BENCH_FUSE_IMAGES"):  # A/B: K-major images by GEMM epilogues (bit 0: h, bit 1: du); 0 = re-layout
+        model.engine.stack.fuse_images = int(os.environ["BENCH_FUSE_IMAGES"])
     if os.environ.get("BENCH_TR_BWD_LAYERS"):  # A/B: K-major X images of the bottom n layers written in backward
         model.engine.stack.tr_bwd_layers = int(os.environ["BENCH_TR_BWD_LAYERS"])
     if os.environ.get("BENCH_TORCH_LOSS", "0") == "1":  # A/B: eager torch loss instead of vl_gqa_loss

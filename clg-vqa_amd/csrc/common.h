@@ -41,7 +41,9 @@ __device__ __forceinline__ void vl_cdf_pdf(float x, float& cdf, float& e) {
   poly = fmaf(poly, t, 1.421413741f);
   poly = fmaf(poly, t, -0.284496736f);
   poly = fmaf(poly, t, 0.254829592f);
-  const float h = 0.5f * poly * t * e;        // 0.5 * (1 - erf(|x|/sqrt2))
+  // (__fmul_rn: the product must not be contracted into the subtraction below -- which instantiation the optimizer
+  // contracts is not stable, and the epilogues of all tile configurations are tested bit-identical)
+  const float h = __fmul_rn(0.5f * poly * t, e);  // 0.5 * (1 - erf(|x|/sqrt2))
   cdf = x >= 0.f ? 1.0f - h : h;
 }
 __device__ __forceinline__ float gelu_erf(float x) {

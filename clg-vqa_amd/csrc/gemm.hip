@@ -25,6 +25,13 @@
 // bank-conflict free on the 64-bank LDS; the next tile's global loads are issued before the MFMA block
 // of the current one.  blockIdx is remapped so that the workgroups resident on one XCD (private L2)
 // walk neighbouring tiles of the same A row-panel.
+#include <type_traits>
+
+// Only the explicit fmaf()s fuse: which a * b + c the optimizer contracts differs between the unrolled instances of an
+// epilogue and between tile configurations, and the epilogues of all configurations are tested bit-identical.
+#ifndef VL_GEMM_CONTRACT_FAST  // (A/B builds only)
+#pragma clang fp contract(off)
+#endif
 #include "common.h"
 #include "../../include/vlhip.h"
 
@@ -80,9 +87,11 @@ __device__ __forceinline__ void image_store(const GemmArgs& p, int m, int n0, co
 // 4 accumulator registers are 4 consecutive n: 16-byte fp32 / 8-byte bf16 accesses instead of scalar ones).
 // want_cs: csum (4 accumulators of the caller) += the rounded out_hi values (column sums for the bias gradient); the
 // accumulators are passed by reference with constant indices only, so they stay in registers
+// lcol (may be NULL) / lpitch: LDS staging of the K-major image (ping-pong kernel): element t goes to lcol[t * lpitch];
+// without it the image is written by 2-byte global stores (correct on every kernel, slow: 32-byte segments)
 template <int EPI>
 __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32, int m, int n0, f32x4 v, bool want_cs,
-                                                float (&csum)[4]) {
+                                                float (&csum)[4], bf16_raw* lcol = nullptr, int lpitch = 0) {
   const bool vec = p.vec && (n0 + 3 < p.N);
   if (vec) {
     if (p.bias) {
@@ -128,7 +137,12 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
       }
       if (p.img || want_cs) {
         const bf16_raw h4[4] = {hi.x, hi.y, hi.z, hi.w};
-        if (p.img) image_store<4>(p, m, n0, h4);
+        if (lcol) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) lcol[t * lpitch] = h4[t];
+        } else if (p.img) {
+          image_store<4>(p, m, n0, h4);
+        }
         if (want_cs) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) csum[t] += bf16_to_f32(h4[t]);
@@ -166,7 +180,8 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
       p.out_lo[(long)m * p.ld16 + n] = lo;
     }
     if (EPI != VL_EPI_F32) {
-      if (p.img) p.img[((long)(m >> 6) * p.img_n + n) * 64 + (m & 63)] = hi;
+      if (lcol) lcol[r * lpitch] = hi;
+      else if (p.img) p.img[((long)(m >> 6) * p.img_n + n) * 64 + (m & 63)] = hi;
       if (want_cs) csum[r] += bf16_to_f32(hi);
     }
   }
@@ -185,10 +200,11 @@ __device__ __forceinline__ uint4 pack8(const ushort4& a, const ushort4& b) {
 }
 template <int EPI>
 __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32, int m, int n0, f32x4 v0, f32x4 v1,
-                                                bool want_cs, float (&c0)[4], float (&c1)[4]) {
+                                                bool want_cs, float (&c0)[4], float (&c1)[4], bf16_raw* lcol = nullptr,
+                                                int lpitch = 0) {
   if (!(p.vec8 && n0 + 7 < p.N)) {
-    epilogue_store4<EPI>(p, out32, m, n0, v0, want_cs, c0);
-    if (n0 + 4 < p.N) epilogue_store4<EPI>(p, out32, m, n0 + 4, v1, want_cs, c1);
+    epilogue_store4<EPI>(p, out32, m, n0, v0, want_cs, c0, lcol, lpitch);
+    if (n0 + 4 < p.N) epilogue_store4<EPI>(p, out32, m, n0 + 4, v1, want_cs, c1, lcol ? lcol + 4 * lpitch : nullptr, lpitch);
     return;
   }
   float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
@@ -236,7 +252,12 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32,
   }
   if (p.img || want_cs) {
     const bf16_raw h8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-    if (p.img) image_store<8>(p, m, n0, h8);
+    if (lcol) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) lcol[t * lpitch] = h8[t];
+    } else if (p.img) {
+      image_store<8>(p, m, n0, h8);
+    }
     if (want_cs) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) { c0[t] += bf16_to_f32(h8[t]); c1[t] += bf16_to_f32(h8[4 + t]); }
@@ -626,11 +647,23 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 
   // epilogue.  D^T layout: lane&15 -> m inside the 16-row tile, 4*(lane>>4) + reg -> n inside the 16-col tile
   float* out32 = p.out32;
+  // K-major image of out_hi: a wave stages its [MI*16 rows] x [2 x NJ*16 columns] part of an M half column-major in a
+  // private LDS region (the K loop is over, LDS is free; 2-byte ds_writes, pitch rows*2 + 8 B: conflict-free), then
+  // writes it as 16-byte chunks of 8 consecutive rows -- 8 lanes cover the 128 contiguous bytes of one column of a
+  // 64-row block.  (Written straight from the accumulator layout it would be 2-byte global stores in 32-byte segments:
+  // measured +75 us per FFN1-sized GEMM, more than the re-layout pass it replaces.)
+  constexpr int IMG_PITCH = MI * 16 * 2 + 8;        // bytes per staged column
+  constexpr int IMG_NCOL = 2 * NJ * 16;             // both N halves of the wave
+  constexpr int IMG_LP = IMG_PITCH / 2;             // pitch in elements
+  unsigned char* limg = smem + wave * (IMG_NCOL * IMG_PITCH);
+  const bool use_limg = EPI != VL_EPI_F32 && p.img != nullptr;
   // (column sums are wired for the GELU' epilogue only -- the one product whose bias gradient needs them; the erf-GELU
   // epilogue on the 256 x 256 tile has no registers to spare for 16 more accumulators)
   const bool want_cs = EPI == VL_EPI_DGELU_BF16 && p.cs != nullptr;
-#pragma unroll
-  for (int qm = 0; qm < 2; ++qm) {
+  // (one call per M half with a compile-time index: as an outer loop the optimizer refuses to unroll it once the body
+  // holds the erf-GELU epilogue and the flush loop, and the accumulators go to scratch)
+  auto half = [&](auto QM) {
+    constexpr int qm = decltype(QM)::value;
     float csum[2][NJ][4];  // column sums of the rounded out_hi values over this wave's rows of the M half
 #pragma unroll
     for (int qn = 0; qn < 2; ++qn)
@@ -641,23 +674,48 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < (qm == 0 ? MI : MI1); ++i) {
       const int m = row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane & 15);
-      if (m >= p.M) continue;
+      const bool row_ok = m < p.M;
+      bf16_raw* lrow = use_limg ? reinterpret_cast<bf16_raw*>(limg) + i * 16 + (lane & 15) : nullptr;
 #pragma unroll
       for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
           const int cb = col0 + qn * BH + wc * (NJ * 16);
           if (j < NJP) {
-            if (j & 1) continue;
-            const int n0 = cb + 32 * (j >> 1) + 8 * (lane >> 4);
-            if (n0 < p.N)
-              epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j], want_cs,
-                                   csum[qn][j], csum[qn][j + 1 < NJ ? j + 1 : j]);
+            if ((j & 1) == 0) {
+              const int nl = 32 * (j >> 1) + 8 * (lane >> 4);  // column inside the wave's NJ*16-wide span
+              const int n0 = cb + nl;
+              if (row_ok && n0 < p.N)
+                epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j], want_cs,
+                                     csum[qn][j], csum[qn][j + 1 < NJ ? j + 1 : j],
+                                     lrow ? lrow + (qn * NJ * 16 + nl) * IMG_LP : nullptr, IMG_LP);
+            }
           } else {
-            const int n0 = cb + j * 16 + 4 * (lane >> 4);
-            if (n0 < p.N) epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j], want_cs, csum[qn][j]);
+            const int nl = j * 16 + 4 * (lane >> 4);
+            const int n0 = cb + nl;
+            if (row_ok && n0 < p.N)
+              epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j], want_cs, csum[qn][j],
+                                   lrow ? lrow + (qn * NJ * 16 + nl) * IMG_LP : nullptr, IMG_LP);
           }
         }
+    }
+    if (EPI != VL_EPI_F32 && use_limg) {  // flush the staged part: 16-byte chunks of 8 consecutive rows of one column
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      constexpr int ROWS = (qm == 0 ? MI : MI1) * 16, CPC = ROWS / 8;
+      const int mbase = row0 + qm * AH + wr * ROWS;
+      for (int idx = lane; idx < IMG_NCOL * CPC; idx += 64) {
+        const int nl = idx / CPC, c = idx - nl * CPC;
+        const int qn = nl / (NJ * 16);
+        const int n = col0 + qn * BH + wc * (NJ * 16) + (nl - qn * (NJ * 16));
+        const int m8 = mbase + c * 8;
+        if (n < p.N && m8 < p.M) {
+          const unsigned char* src = limg + nl * IMG_PITCH + c * 16;
+          const uint2 lo8 = *reinterpret_cast<const uint2*>(src), hi8 = *reinterpret_cast<const uint2*>(src + 8);
+          *reinterpret_cast<uint4*>(p.img + ((long)(m8 >> 6) * p.img_n + n) * 64 + (m8 & 63)) =
+              make_uint4(lo8.x, lo8.y, hi8.x, hi8.y);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (EPI == VL_EPI_DGELU_BF16 && want_cs) {  // one partial row per (tile row, M half, wave row): sum over the 16 row lanes, then store
       float* dst = p.cs + (long)((tm * 2 + qm) * WR + wr) * p.N;
@@ -682,7 +740,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
           }
         }
     }
-  }
+  };
+  half(std::integral_constant<int, 0>{});
+  half(std::integral_constant<int, 1>{});
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -73,12 +73,18 @@ int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, cons
 // The two [M, I] operands of the weight-gradient GEMMs -- GELU output h (X side of dW2) and du (dY side of dW1, + the
 // column sums that are b1's gradient) -- are written as K-major images by the epilogues of the GEMMs that produce them
 // when those run on the ping-pong kernel over whole 64-row blocks: half of the re-layout traffic never happens.
-bool fused_images(const int64_t* d, int64_t l) {
+bool fused_shape(const int64_t* d, int64_t l) {
   const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I], L = d[VL_ST_NLAYERS], M = B * S;
   const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;
+  return !pooled && M % 64 == 0 && vl_gemm_nt_path(M, I, H, 1, d[VL_ST_SMALL_WS] != 0) == 2;
+}
+bool fused_h(const int64_t* d, int64_t l) {  // VL_ST_FUSE_IMAGES bit 0: h by the FFN1 (erf-GELU) epilogue
   const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
-  return !pooled && M % 64 == 0 && y[VL_LY_T_H] && y[VL_LY_T_DU] && y[VL_LY_CS_DU] &&
-         vl_gemm_nt_path(M, I, H, 1, d[VL_ST_SMALL_WS] != 0) == 2;
+  return (d[VL_ST_FUSE_IMAGES] & 1) && y[VL_LY_T_H] && fused_shape(d, l);
+}
+bool fused_du(const int64_t* d, int64_t l) {  // bit 1: du + its column sums by the GELU' epilogue
+  const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
+  return (d[VL_ST_FUSE_IMAGES] & 2) && y[VL_LY_T_DU] && y[VL_LY_CS_DU] && fused_shape(d, l);
 }
 
 int check_header(const char* fn, const int64_t* d) {
@@ -105,7 +111,7 @@ int x_images(const int64_t* d, int64_t l, int64_t max_blocks, hipStream_t ss) {
     VL_TRY(vl_transpose_blocked(tr, 1, M, max_blocks, ss));
     return vl_transpose_blocked(tr + VL_TR_FIELDS, 3, B, max_blocks, ss);
   }
-  return vl_transpose_blocked(tr, fused_images(d, l) ? 3 : 4, M, max_blocks, ss);  // (h: by the FFN1 epilogue)
+  return vl_transpose_blocked(tr, fused_h(d, l) ? 3 : 4, M, max_blocks, ss);  // (h: by the FFN1 epilogue)
 }
 
 }  // namespace
@@ -180,7 +186,7 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
     const GemmImage him{ptr<void>(y[VL_LY_T_H]), I, nullptr, nullptr};
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), H, ptr<void>(y[VL_LY_W1_HI]), ptr<void>(y[VL_LY_W1_LO]), H,
                 R, I, H, 3, VL_EPI_GELU_SPLIT, ptr<const float>(y[VL_LY_B1]), nullptr, nullptr, 0, ptr<void>(y[VL_LY_H_HI]),
-                ptr<void>(y[VL_LY_H_LO]), ptr<void>(y[VL_LY_U16]), I, stream, fused_images(d, l) ? &him : nullptr));
+                ptr<void>(y[VL_LY_H_LO]), ptr<void>(y[VL_LY_U16]), I, stream, fused_h(d, l) ? &him : nullptr));
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_H_HI]), ptr<void>(y[VL_LY_H_LO]), I, ptr<void>(y[VL_LY_W2_HI]), ptr<void>(y[VL_LY_W2_LO]), I,
                 R, H, I, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_B2]), nullptr, ptr<float>(y[VL_LY_Z2]), H, nullptr, nullptr,
                 nullptr, 0, stream));
@@ -237,7 +243,7 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
                      ptr<const float>(y[VL_LY_RSTD2]), ptr<const float>(y[VL_LY_LN2_G]), nullptr, row_post, ptr<float>(y[VL_LY_DZ2]),
                      ptr<void>(y[VL_LY_DT2]), nullptr, nullptr, nullptr, nullptr, ptr<float>(y[VL_LY_LNWS2]), R, H, R, 0, 0, p_hid, 0.f,
                      seed_of(d[VL_ST_SEED0], s3 + 2), os, sm));
-    const bool fused = fused_images(d, l);
+    const bool fused = fused_du(d, l);
     int64_t cs_du_rows = 0;
     const GemmImage duim{ptr<void>(y[VL_LY_T_DU]), I, ptr<float>(y[VL_LY_CS_DU]), &cs_du_rows};
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_DT2]), nullptr, H, ptr<void>(y[VL_LY_W2_T]), nullptr, H, R, I, H, 1, VL_EPI_DGELU_BF16,

@@ -132,7 +132,19 @@ def dw_gemm(dy16, x16, M, N, K, mask=None):
         tA = ops._tmp(torch.empty(lib.vl_blocked_elems(M, N), dtype=BF16, device=dev))
         tB = ops._tmp(torch.empty(lib.vl_blocked_elems(M, K), dtype=BF16, device=dev))
         ops.transpose_blocked([(dy16, tA, None), (x16, tB, None)], M)
-        ops.dw_grouped([(tA, 0, N, tB, K, dW, mask, N, K)], M)
+        # few output tiles x many rows (the image-embedding Linear: 24 tiles x 9216 rows): split the rows over up to 8
+        # problems of one launch (fp32 slabs, summed in a fixed order) so that the grid covers the chip
+        tiles, nblk = ((N + 255) // 256) * ((K + 255) // 256), M // 64
+        parts = max([s_ for s_ in range(1, 9) if M % 64 == 0 and nblk % s_ == 0 and tiles * s_ <= 256 and nblk // s_ >= 8]
+                    or [1])
+        if parts == 1:
+            ops.dw_grouped([(tA, 0, N, tB, K, dW, mask, N, K)], M)
+            return dW
+        slabs = ops._tmp(torch.empty(parts, N * K, dtype=torch.float32, device=dev))
+        rows = M // parts
+        ops.dw_grouped([(tA[i * rows * N:], 0, N, tB[i * rows * K:], K, slabs[i].view(N, K), mask, N, K)
+                        for i in range(parts)], rows)
+        ops.colreduce_multi([(slabs, N * K, (dW,))])
         return dW
     if ops.gemm_tn_splitk(dy16, x16, N, K, M, dW):
         return dW if mask is None else ops.mask_mul(dW, mask, dW)
@@ -228,7 +240,7 @@ class StackArena(object):
             self.t_x, self.t_ctx, self.t_x1, self.t_h = b16(L, nx), b16(L, nx), b16(L, nx), b16(L, ni)
             # du's image + its column-sum partials per layer: written by the GELU' epilogue on the main stream while the
             # side stream may still be reading the layer above's
-            self.t_du_l, self.cs_du_l = b16(L, ni), f32(L, 4 * ((M + 223) // 224), I)
+            self.t_du_l, self.cs_du_l = b16(L, ni), f32(L, 8 * ((M + 255) // 256), I)
             mb = (M + 63) // 64
             self.cs_qkv, self.cs_u = f32(mb, 3 * H), f32(mb, I)
             self.fork = torch.cuda.Event()
@@ -250,7 +262,11 @@ class LayerStack(object):
         # last layer then runs on the B live rows after its K/V projection and the stack returns [B, 1, H] (exact: the
         # live rows are bit-identical to the dense run, the dead ones are never computed)
         self.pooled_only = True
-        self.fuse_images = True  # h / du K-major images written by the GEMM epilogues (A/B knob; False = re-layout pass)
+        # K-major images written by GEMM epilogues instead of the re-layout pass: bit 0 = h (FFN1 forward), bit 1 = du +
+        # its column sums (FFN1 backward).  Measured at c2 (same box): 0 -> 17.40, 1 -> 17.56, 2 -> 17.58, 3 -> 17.61 ms:
+        # the image is 88 MB more HBM writes in an epilogue all CUs reach together (+17 us per FFN1 forward, +46 us per
+        # backward), on the critical path, while the re-layout pass it saves runs beside the GEMMs on the side stream -> off
+        self.fuse_images = 0
         self.tr_blocks = (0, 0)  # workgroup caps of the K-major re-layout launches (forward, backward); 0 = default
         # K-major X images: the bottom `tr_bwd_layers` layers' are written in backward on the side stream, the others at
         # the end of forward, in the window of the task head.  None = all but the top layer: since the head became one
@@ -342,8 +358,7 @@ class LayerStack(object):
                 put("DZ2", ar.dz2); put("DX1", ar.dx1); put("DZ1", ar.dz1); put("DCTX16", ar.dctx16)
                 for name in ("dt2", "du16", "dt1", "dqkv", "lnws1", "lnws2", "t_x", "t_ctx", "t_x1", "t_h"):
                     put(name.upper(), getattr(ar, name)[l])
-                if self.fuse_images:
-                    put("T_DU", ar.t_du_l[l]); put("CS_DU", ar.cs_du_l[l])
+                put("T_DU", ar.t_du_l[l]); put("CS_DU", ar.cs_du_l[l])
         self._desc[id(ar)] = (fp, d)
         return d
 
@@ -361,6 +376,7 @@ class LayerStack(object):
         d[VL["VL_ST_POOLED_ONLY"]] = 1 if self.pooled_only else 0
         d[VL["VL_ST_TR_BLOCKS_FWD"]], d[VL["VL_ST_TR_BLOCKS_BWD"]] = self.tr_blocks
         d[VL["VL_ST_TR_BWD_LAYERS"]] = len(self.specs) - 1 if self.tr_bwd_layers is None else self.tr_bwd_layers
+        d[VL["VL_ST_FUSE_IMAGES"]] = self.fuse_images
         side_ptr = None
         if ar.need_grad and self.overlap_dw:
             dev = ar.x32.device

@@ -64,7 +64,7 @@ int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi
  *              when M is a multiple of 64, or zero them.
  *  VL_GX_COLSUM  (DGELU epilogue, ping-pong kernel only -- vl_gemm_nt_path() == 2) fp32 [rows, N] partial column sums of
  *              the rounded out_hi values, the bias-gradient partials the re-layout pass used to produce; on return
- *              VL_GX_COLSUM_ROWS holds the number of partial rows written (<= 4 * ceil(M / 224)): sum them with
+ *              VL_GX_COLSUM_ROWS holds the number of partial rows written (<= 8 * ceil(M / 256)): sum them with
  *              vl_colreduce_multi. */
 enum { VL_GX_TILE = 0, VL_GX_WS = 1, VL_GX_WS_FLOATS = 2, VL_GX_IMG = 3, VL_GX_IMG_COLS = 4, VL_GX_COLSUM = 5,
        VL_GX_COLSUM_ROWS = 6, VL_GX_FIELDS = 8 };
@@ -255,6 +255,8 @@ enum {
   VL_ST_SMALL_WS_FLOATS = 31,
   VL_ST_TR_BWD_LAYERS = 32, /* K-major X images: those of the bottom n layers are written in backward (side stream, ahead of the
                                layer's own re-layout), the others at the end of forward (under the task head); 0 = all in forward */
+  VL_ST_FUSE_IMAGES = 33, /* bit 0: the FFN1 epilogue writes the K-major image of the GELU output (VL_LY_T_H); bit 1: the GELU'
+                             epilogue of FFN1's backward writes du's image + column sums (VL_LY_T_DU / VL_LY_CS_DU) */
   VL_ST_FIELDS = 40
 };
 enum {
@@ -319,7 +321,7 @@ enum {
   VL_LY_T_CTX = 78,
   VL_LY_T_X1 = 79,
   VL_LY_T_H = 80,
-  VL_LY_T_DU = 81, /* per-layer K-major image of du16 + its column-sum partials [4 * ceil(M / 224), I]: written by the GELU'
+  VL_LY_T_DU = 81, /* per-layer K-major image of du16 + its column-sum partials [8 * ceil(M / 256), I]: written by the GELU'
                       epilogue of the FFN1-backward GEMM on the MAIN stream while the side stream may still read the layer
                       above's (0 = use the shared VL_ST_T_DU / VL_ST_CS_U through the re-layout pass) */
   VL_LY_CS_DU = 82,

@@ -893,7 +893,7 @@ def test_gemm_epilogue_writes_the_kmajor_image_and_column_sums(M, N, K, tile):
     assert torch.equal(hi, hi0)  # the row-major outputs do not change
     # backward: GELU' multiply + bf16, image + column sums
     du = torch.empty(M, N, dtype=BF16, device=DEV)
-    cs = torch.full((4 * ((M + 223) // 224), N), float("nan"), device=DEV)
+    cs = torch.full((8 * ((M + 255) // 256), N), float("nan"), device=DEV)
     img.fill_(float("nan"))
     rows = ops.gemm_nt(a, None, b, None, M, N, K, 1, EPI_DGELU_BF16, out_hi=du, aux16=aux, tile=tile, image=img, colsum=cs)
     assert 0 < rows <= cs.shape[0]
