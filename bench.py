@@ -238,6 +238,8 @@ def main():
             masked_elems += w.numel()
     if os.environ.get("BENCH_TR_BLOCKS"):  # A/B: workgroup caps of the K-major re-layout launches, "fwd,bwd"
         model.engine.stack.tr_blocks = tuple(int(x) for x in os.environ["BENCH_TR_BLOCKS"].split(","))
+    if os.environ.get("BENCH_DW_ROWMAJOR"):  # A/B: 0 = weight gradients through the K-major re-layout pass
+        model.engine.stack.dw_rowmajor = os.environ["BENCH_DW_ROWMAJOR"] != "0"
     if os.environ.get("BENCH_FUSE_IMAGES"):  # A/B: K-major images by GEMM epilogues (bit 0: h, bit 1: du); 0 = re-layout
         model.engine.stack.fuse_images = int(os.environ["BENCH_FUSE_IMAGES"])
     if os.environ.get("BENCH_TR_BWD_LAYERS"):  # A/B: K-major X images of the bottom n layers written in backward
@@ -251,6 +253,8 @@ def main():
     if os.environ.get("BENCH_NO_SMALL_GEMM", "0") == "1":  # A/B: batch-sized products on the big-tile kernels
         from clg_vqa_amd import ops as _ops
         _ops.SMALL_GEMM = False
+    if os.environ.get("BENCH_SIDE_PRIORITY"):  # A/B: queue priority of the weight-gradient stream (default: lowest)
+        model.engine.stack.side_priority = int(os.environ["BENCH_SIDE_PRIORITY"])
     if os.environ.get("BENCH_NO_OVERLAP", "0") == "1":  # A/B: weight-gradient work on the main stream
         model.engine.stack.overlap_dw = False
     model.train()
@@ -279,6 +283,10 @@ def main():
         host[2] += c3 - c2
         return loss
 
+    if os.environ.get("BENCH_MAIN_HIGH", "0") == "1":  # A/B: the training step on a high-priority stream
+        hp = torch.cuda.Stream(device=dev, priority=-1)
+        hp.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(hp)
     for _ in range(args.warmup):
         step()
     if world > 1:

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(CsArgs a) {
 // latency-bound launches, four of them per layer on the weight-gradient stream otherwise.  256 threads = 64 columns x 4
 // row groups (256-byte contiguous reads per row), fixed summation order (deterministic).
 struct CrSet { const float* src; int nrows; int ncols; int seg; float* out[3]; };
-struct CrArgs { CrSet set[4]; int n; int accumulate; };
+struct CrArgs { CrSet set[8]; int n; int accumulate; };
 __global__ __launch_bounds__(256) void colreduce_multi_kernel(CrArgs a) {
   __shared__ float red[4][64];
   const CrSet& st = a.set[blockIdx.y];
@@ -160,6 +160,9 @@ struct DwProb {
   float* out; const float* mask; long ldo;
   int M, N;                              // output rows (dY columns of this problem) x columns (X columns)
   int tile0, tiles_n;
+  // row-major form (TN): a = dY [rows, lda] at this problem's first column, b = X [rows, ldb]; ka / kb = 64 * ld;
+  // cs (may be NULL): fp32 [tiles_n, M] partial column sums of dY (the bias gradient; see below)
+  long lda, ldb; float* cs;
 };
 struct DwArgs { DwProb p[MAXT]; int nprob; int nk; int total_tiles; int accumulate; };
 
@@ -167,6 +170,34 @@ __device__ __forceinline__ int swz3(int row) {
   return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 4) ^ (row >> 2)) & 1) << 2);
 }
 
+// TN = true: the operands are the ROW-MAJOR activations themselves (dY [rows, N_out], X [rows, K_in], rows = the reduction
+// dimension) -- no K-major images, no re-layout pass.  A K-tile is 64 rows; a half-tile is [64 rows][128 columns] (256-B
+// rows, 16 KB like the NT half-tile, so staging units, DMA instruction counts and the vmcnt accounting are unchanged);
+// MFMA fragments (8 consecutive rows of one column per lane) are gathered with ds_read_b64_tr_b16 -- two 4(row) x
+// 16(column) transposing block reads per fragment, the same LDS bytes per MFMA as the NT form.  32-byte column blocks are
+// XOR-swizzled with h(row) = (row & 3) | ((row >> 3) & 1) << 2 on the DMA source address and undone by the reads: the 8
+// rows a 32-lane half touches hit 8 different 32-byte bank groups.  Needs rows % 64 == 0 and M, N multiples of 8.
+// Bias gradients (column sums of dY over the rows) come out of the same pass: the waves with wc == 0 add up the A
+// fragments they hold anyway (VALU, in the load section) for the K-tiles kt = tn (mod tiles_n) of their tile row, so the
+// tiles of a row share the work; partial row tn of cs is summed by vl_colreduce_multi.
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0) {
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * 256));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ float frag_sum(const bf16x8& f) {  // sum of the 8 bf16 values (fp32)
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  const u32x4 w = __builtin_bit_cast(u32x4, f);
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) s += __uint_as_float(w[t] << 16) + __uint_as_float(w[t] & 0xFFFF0000u);
+  return s;
+}
+
+template <bool TN>
 __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   constexpr int WC = 4;                        // wave grid 2 (M) x 4 (N)
   constexpr int MI = 4, NJ = 2;                // 16 x 16 MFMA tiles per quadrant
@@ -198,12 +229,22 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool isB = x >= 2;
-      const int r = 8 * (wave + 8 * j) + (lane >> 3);
-      const int lc = (lane & 7) ^ swz3(r);
-      int g = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + r;
-      const int lim = (isB ? P.N : P.M) - 1;
-      g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
-      src[x][j] = (isB ? P.b : P.a) + (long)g * 64 + lc * 8;
+      if (TN) {
+        const int r = 4 * (wave + 8 * j) + (lane >> 4);  // row of the K-tile; unit = 4 rows x 256 B
+        const int c = lane & 15;                         // physical 16-byte chunk of the row
+        const int lb = (c >> 1) ^ ((r & 3) | (((r >> 3) & 1) << 2));  // logical 32-B block landing at physical c >> 1
+        int gcol = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + lb * 16 + (c & 1) * 8;
+        const int lim = (isB ? P.N : P.M) - 8;
+        gcol = gcol < lim ? gcol : lim;  // columns past the edge re-read valid data; their products are never stored
+        src[x][j] = (isB ? P.b : P.a) + (long)r * (isB ? P.ldb : P.lda) + gcol;
+      } else {
+        const int r = 8 * (wave + 8 * j) + (lane >> 3);
+        const int lc = (lane & 7) ^ swz3(r);
+        int g = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + r;
+        const int lim = (isB ? P.N : P.M) - 1;
+        g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
+        src[x][j] = (isB ? P.b : P.a) + (long)g * 64 + lc * 8;
+      }
     }
   const long kstep[2] = {P.ka, P.kb};
   constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
@@ -232,30 +273,58 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 
   const int frow = lane & 15, fk = lane >> 4;
   int a_o[MI][2], b_o[NJ][2];
+  if (TN) {
+    // transposed-read lane geometry: group fk owns rows 8 fk .. 8 fk + 7 of a 32-deep step; inside the group lane
+    // 4 q + pp addresses row q, columns 4 pp .. 4 pp + 3 of the 4 x 16 block (the second read is 4 rows below)
+    const int q = (lane & 15) >> 2, pp = lane & 3, hq = q | ((fk & 1) << 2);
 #pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    const int row = wr * (MI * 16) + i * 16 + frow;
-    a_o[i][0] = row * 128 + ((fk ^ swz3(row)) << 4);
-    a_o[i][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
-  }
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int row = wc * (NJ * 16) + j * 16 + frow;
-    b_o[j][0] = row * 128 + ((fk ^ swz3(row)) << 4);
-    b_o[j][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+      for (int kk = 0; kk < 2; ++kk) a_o[i][kk] = (kk * 32 + 8 * fk + q) * 256 + (((wr * MI + i) ^ hq) << 5) + pp * 8;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) b_o[j][kk] = (kk * 32 + 8 * fk + q) * 256 + (((wc * NJ + j) ^ hq) << 5) + pp * 8;
+  } else {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = wr * (MI * 16) + i * 16 + frow;
+      a_o[i][0] = row * 128 + ((fk ^ swz3(row)) << 4);
+      a_o[i][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int row = wc * (NJ * 16) + j * 16 + frow;
+      b_o[j][0] = row * 128 + ((fk ^ swz3(row)) << 4);
+      b_o[j][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+    }
   }
+  float bsum[2][MI];  // TN: column sums of dY for this wave's output rows (bias gradient partials)
+#pragma unroll
+  for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+    for (int i = 0; i < MI; ++i) bsum[qm][i] = 0.f;
+  const bool bias_wave = TN && P.cs != nullptr && wc == 0;
 
   bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
+#define DW_FRAG(ptr) (TN ? tr_frag(ptr) : *reinterpret_cast<const bf16x8*>(ptr))
 #define DW_READ_A(st, qm)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
-    fa[i][0] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[i][0]);                               \
-    fa[i][1] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[i][1]);                               \
+    fa[i][0] = DW_FRAG((st) + (qm) * OFF_A1 + a_o[i][0]);                                                        \
+    fa[i][1] = DW_FRAG((st) + (qm) * OFF_A1 + a_o[i][1]);                                                        \
   }
 #define DW_READ_B(st, qn, fb)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
-    fb[j][0] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                  \
-    fb[j][1] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                  \
+    fb[j][0] = DW_FRAG((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                                           \
+    fb[j][1] = DW_FRAG((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                                           \
   }
+  // (after the MFMA section of a quadrant that consumed fresh A fragments: their column sums, on the selected K-tiles)
+#define DW_BIAS(qm)                                                                                              \
+  do {                                                                                                           \
+    if (TN && bias_now) {                                                                                        \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) bsum[qm][i] += frag_sum(fa[i][0]) + frag_sum(fa[i][1]);     \
+    }                                                                                                            \
+  } while (0)
 #define DW_MFMA(qm, qn, fb)                                                                                      \
   do {                                                                                                           \
     __builtin_amdgcn_s_barrier();                                                                                \
@@ -285,6 +354,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    const bool bias_now = bias_wave && (kt % P.tiles_n) == tn;
     DW_READ_B(st, 0, fb0);
     __builtin_amdgcn_sched_barrier(0);
     DW_READ_A(st, 0);
@@ -295,6 +365,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     if (n1) DW_ISSUE(1, kt + 1);
     DW_WAIT(n1);
     DW_MFMA(0, 1, fb1);
+    DW_BIAS(0);
     DW_READ_A(st, 1);
     if (n2) DW_ISSUE(0, kt + 2);
     DW_WAIT(n2);
@@ -302,6 +373,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     if (n2) DW_ISSUE(2, kt + 2);
     DW_WAIT(n2);
     DW_MFMA(1, 0, fb0);
+    DW_BIAS(1);
   }
   if (!late) __builtin_amdgcn_s_barrier();
 #undef DW_ISSUE
@@ -309,6 +381,21 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 #undef DW_READ_A
 #undef DW_READ_B
 #undef DW_MFMA
+#undef DW_FRAG
+#undef DW_BIAS
+
+  if (TN && bias_wave) {  // rows 8 fk .. 8 fk + 7 of every 32-deep step were summed per lane group: add the 4 groups
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        float v = bsum[qm][i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int m = row0 + qm * AH + wr * (MI * 16) + i * 16 + (lane & 15);
+        if (lane < 16 && m < P.M) P.cs[(long)tn * P.M + m] = v;
+      }
+  }
 
   // epilogue: lane & 15 -> output row (dY column), 4 * (lane >> 4) + reg -> 4 consecutive output columns
 #pragma unroll
@@ -398,7 +485,7 @@ extern "C" int vl_colsum_finalize(const float* partial, int64_t nblk, int64_t N,
 // tab: HOST array of n (<= 4) x VL_CR_FIELDS int64 {src, nrows, ncols, seg, out0, out1, out2, 0}: out_t[c] (+)= sum_rows
 // src[row][t * seg + c] (a NULL out_t skips that segment)
 extern "C" int vl_colreduce_multi(const int64_t* tab, int64_t n, int accumulate, void* stream) {
-  VL_CHECK_ARG(tab && n >= 1 && n <= 4, "vl_colreduce_multi: bad arguments");
+  VL_CHECK_ARG(tab && n >= 1 && n <= 8, "vl_colreduce_multi: bad arguments");
   CrArgs a{};
   a.n = (int)n; a.accumulate = accumulate;
   int maxc = 0;
@@ -417,8 +504,11 @@ extern "C" int vl_colreduce_multi(const int64_t* tab, int64_t n, int accumulate,
 }
 
 // probs: HOST array of nprob x VL_DW_FIELDS int64 {aT, a_rows_total, bT, b_rows_total, out, ldo, mask (0 = none), M, N, 0}
-extern "C" int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream) {
-  VL_CHECK_ARG(probs && nprob >= 1 && nprob <= MAXT && K >= 1, "vl_dw_grouped: bad arguments");
+// (rowmajor: {dY, lda, X, ldb, out, ldo, mask, M, N, colsum partials [ceil(N / 256), M] or 0})
+static int dw_launch(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, bool rowmajor, void* stream) {
+  const char* fn = rowmajor ? "vl_dw_grouped_rowmajor" : "vl_dw_grouped";
+  VL_CHECK_ARG(probs && nprob >= 1 && nprob <= MAXT && K >= 1, "%s: bad arguments", fn);
+  VL_CHECK_ARG(!rowmajor || K % 64 == 0, "%s: the row count must be a multiple of 64 (got %lld)", fn, (long long)K);
   DwArgs a{};
   a.nprob = (int)nprob; a.nk = (int)((K + 63) / 64); a.accumulate = accumulate;
   int tiles = 0;
@@ -426,25 +516,38 @@ extern "C" int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int
     const int64_t* t = probs + i * VL_DW_FIELDS;
     DwProb& p = a.p[i];
     p.a = (const bf16_raw*)t[0]; p.ka = t[1] * 64; p.b = (const bf16_raw*)t[2]; p.kb = t[3] * 64;
+    p.lda = t[1]; p.ldb = t[3];
     p.out = (float*)t[4]; p.ldo = t[5]; p.mask = (const float*)t[6]; p.M = (int)t[7]; p.N = (int)t[8];
+    p.cs = rowmajor ? (float*)t[9] : nullptr;
     VL_CHECK_ARG(p.a && p.b && p.out && p.M > 0 && p.N > 0 && t[1] >= p.M && t[3] >= p.N && p.ldo >= p.N,
-                 "vl_dw_grouped: problem %d: bad pointers / sizes", i);
+                 "%s: problem %d: bad pointers / sizes", fn, i);
     VL_CHECK_ARG(al16(p.a) && al16(p.b) && al16(p.out) && al16(p.mask) && (p.ldo & 3) == 0,
-                 "vl_dw_grouped: problem %d: pointers must be 16-byte aligned, ldo a multiple of 4", i);
+                 "%s: problem %d: pointers must be 16-byte aligned, ldo a multiple of 4", fn, i);
+    VL_CHECK_ARG(!rowmajor || ((p.M & 7) == 0 && (p.N & 7) == 0 && p.M >= 8 && p.N >= 8 && (t[1] & 7) == 0 && (t[3] & 7) == 0),
+                 "%s: problem %d: M, N and the leading dimensions must be multiples of 8", fn, i);
     p.tile0 = tiles;
     p.tiles_n = (p.N + 255) / 256;
     tiles += ((p.M + 255) / 256) * p.tiles_n;
   }
   a.total_tiles = tiles;
   const size_t lds = 2 * 65536;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_grouped_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return vl_set_error(-3, "vl_dw_grouped: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+  static bool attr_set[2] = {false, false};
+  const void* kfn = rowmajor ? reinterpret_cast<const void*>(&dw_grouped_kernel<true>)
+                             : reinterpret_cast<const void*>(&dw_grouped_kernel<false>);
+  if (!attr_set[rowmajor]) {
+    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vl_set_error(-3, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    attr_set[rowmajor] = true;
   }
-  hipLaunchKernelGGL(dw_grouped_kernel, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a);
-  VL_CHECK_LAUNCH("vl_dw_grouped");
+  if (rowmajor) hipLaunchKernelGGL(dw_grouped_kernel<true>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(dw_grouped_kernel<false>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a);
+  VL_CHECK_LAUNCH(fn);
   return 0;
+}
+
+extern "C" int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream) {
+  return dw_launch(probs, nprob, K, accumulate, false, stream);
+}
+extern "C" int vl_dw_grouped_rowmajor(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, void* stream) {
+  return dw_launch(probs, nprob, rows, accumulate, true, stream);
 }

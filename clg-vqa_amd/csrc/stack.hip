@@ -73,6 +73,12 @@ int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, cons
 // The two [M, I] operands of the weight-gradient GEMMs -- GELU output h (X side of dW2) and du (dY side of dW1, + the
 // column sums that are b1's gradient) -- are written as K-major images by the epilogues of the GEMMs that produce them
 // when those run on the ping-pong kernel over whole 64-row blocks: half of the re-layout traffic never happens.
+// weight gradients from the row-major activations (no K-major images at all): whole 64-row blocks only
+bool dw_rowmajor(const int64_t* d) {
+  const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I];
+  return d[VL_ST_DW_ROWMAJOR] != 0 && (B * S) % 64 == 0 && (d[VL_ST_POOLED_ONLY] == 0 || B % 64 == 0) && H % 8 == 0 &&
+         I % 8 == 0 && d[VL_ST_CS_QKV] && d[VL_ST_CS_U];
+}
 bool fused_shape(const int64_t* d, int64_t l) {
   const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I], L = d[VL_ST_NLAYERS], M = B * S;
   const bool pooled = d[VL_ST_POOLED_ONLY] != 0 && l == L - 1;
@@ -202,7 +208,7 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
   // layer's own re-layout.  History: written layer by layer beside the forward GEMMs the re-layout cost the QKV
   // projection +40 % (net zero); all 12 layers under the head was best while the head was ~75 eager launches (0.6 ms);
   // with the head as one native node (~0.3 ms) only the top layer's images still fit there (16.98 vs 17.28 ms / step).
-  if (layer_end == L && d[VL_ST_FIELDS + VL_LY_T_X]) {
+  if (layer_end == L && d[VL_ST_FIELDS + VL_LY_T_X] && !dw_rowmajor(d)) {
     if (ss != (hipStream_t)stream) {
       VL_CHECK_ARG(fork, "vl_stack_fwd: a side stream needs the fork event of the descriptor");
       hipError_t e = hipEventRecord(fork, (hipStream_t)stream);
@@ -272,6 +278,37 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
     if (pooled)
       VL_TRY(vl_embed_scatter_add(ptr<const int64_t>(d[VL_ST_ROWS0]), ptr<const float>(y[VL_LY_DZ1]), ptr<float>(y[VL_LY_DX]), B, H,
                                   -1, nullptr, sm));
+    // ---- optimizer-only work (side stream): weight-gradient GEMM + column sums ------------------------------------
+    const int64_t nws = vl_ln_bwd_ws_floats(R, H) / (3 * H);
+    if (dw_rowmajor(d)) {
+      // straight from the row-major activations: one grouped launch, the bias column sums of dqkv / du ride in it
+      // (partials [3][.] per problem in the CS buffers), one column-reduction launch after it
+      const int64_t tq = (H + 255) / 256;  // partial rows of a problem whose X operand has H columns
+      float* csq = ptr<float>(d[VL_ST_CS_QKV]);
+      const int64_t cq = (int64_t)(uintptr_t)csq, ck = (int64_t)(uintptr_t)(csq + tq * H), cv = (int64_t)(uintptr_t)(csq + 2 * tq * H);
+      const int64_t pr[6 * VL_DW_FIELDS] = {
+          y[VL_LY_DQKV], 3 * H, y[VL_LY_X_HI], H, y[VL_LY_GRAD0 + 0], H, y[VL_LY_MASK0 + 0], H, H, cq,
+          y[VL_LY_DQKV] + 2 * H, 3 * H, y[VL_LY_X_HI], H, y[VL_LY_GRAD0 + 2], H, y[VL_LY_MASK0 + 1], H, H, ck,
+          y[VL_LY_DQKV] + 4 * H, 3 * H, y[VL_LY_X_HI], H, y[VL_LY_GRAD0 + 4], H, y[VL_LY_MASK0 + 2], H, H, cv,
+          y[VL_LY_DT1], H, y[VL_LY_CTX_HI], H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
+          y[VL_LY_DU16], I, y[VL_LY_X1_HI], H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, d[VL_ST_CS_U],
+          y[VL_LY_DT2], H, y[VL_LY_H_HI], I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
+      if (pooled) {  // Q/K/V gradients reduce over all M rows, the other three over the B live rows
+        VL_TRY(vl_dw_grouped_rowmajor(pr, 3, M, accumulate, ss));
+        VL_TRY(vl_dw_grouped_rowmajor(pr + 3 * VL_DW_FIELDS, 3, R, accumulate, ss));
+      } else {
+        VL_TRY(vl_dw_grouped_rowmajor(pr, 6, M, accumulate, ss));
+      }
+      const int64_t cr[6 * VL_CR_FIELDS] = {
+          y[VL_LY_LNWS2], nws, 3 * H, H, y[VL_LY_GRAD0 + 14], y[VL_LY_GRAD0 + 15], y[VL_LY_GRAD0 + 13], 0,
+          y[VL_LY_LNWS1], nws, 3 * H, H, y[VL_LY_GRAD0 + 8], y[VL_LY_GRAD0 + 9], y[VL_LY_GRAD0 + 7], 0,
+          cq, tq, H, H, y[VL_LY_GRAD0 + 1], 0, 0, 0,
+          ck, tq, H, H, y[VL_LY_GRAD0 + 3], 0, 0, 0,
+          cv, tq, H, H, y[VL_LY_GRAD0 + 5], 0, 0, 0,
+          d[VL_ST_CS_U], tq, I, I, y[VL_LY_GRAD0 + 11], 0, 0, 0};
+      VL_TRY(vl_colreduce_multi(cr, 6, accumulate, ss));
+      continue;
+    }
     // ---- optimizer-only work: K-major re-layout, column sums, grouped weight-gradient GEMM ---------------------------
     const int64_t mblk = (M + 63) / 64, rblk = (R + 63) / 64;
     const int64_t tr[4 * VL_TR_FIELDS] = {
@@ -291,7 +328,6 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
     }
     // one launch: LayerNorm partials -> (dgamma, dbeta, bias gradient of the producing Linear) x 2, column-sum partials
     // of dqkv -> (bq, bk, bv) and of du -> b1
-    const int64_t nws = vl_ln_bwd_ws_floats(R, H) / (3 * H);
     const int64_t cr[4 * VL_CR_FIELDS] = {
         y[VL_LY_LNWS2], nws, 3 * H, H, y[VL_LY_GRAD0 + 14], y[VL_LY_GRAD0 + 15], y[VL_LY_GRAD0 + 13], 0,
         y[VL_LY_LNWS1], nws, 3 * H, H, y[VL_LY_GRAD0 + 8], y[VL_LY_GRAD0 + 9], y[VL_LY_GRAD0 + 7], 0,

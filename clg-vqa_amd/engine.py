@@ -258,6 +258,10 @@ class LayerStack(object):
     def __init__(self, specs, H, nh, I, eps):
         self.specs, self.H, self.nh, self.I, self.eps = specs, H, nh, I, eps
         self.overlap_dw = True   # weight-gradient work on a second HIP stream (A/B knob)
+        self.side_priority = None
+        # weight gradients straight from the row-major activations (transposing LDS reads in the dW GEMM) whenever B*S is
+        # a multiple of 64: no K-major images, no re-layout pass (False = the K-major path, also the fallback)
+        self.dw_rowmajor = True
         # the heads of this path read hidden_states[:, 0] only (BertTextPooler encoders.py:597-608, M3P BertPooler): the
         # last layer then runs on the B live rows after its K/V projection and the stack returns [B, 1, H] (exact: the
         # live rows are bit-identical to the dense run, the dead ones are never computed)
@@ -282,6 +286,14 @@ class LayerStack(object):
         self._arenas = {}
         self._desc = {}
         self.prof = None  # numpy int64 VlProf block (bench.py): GEMM launch timing by caller-owned events
+
+    def _new_side_stream(self, dev):
+        # optimizer-only work must not starve the critical path of CUs: the side stream gets the LOWEST queue priority
+        # (side_priority: None = lowest the runtime offers; an int = that priority)
+        pr = self.side_priority
+        if pr is None:
+            pr = max(torch.cuda.Stream.priority_range())
+        return torch.cuda.Stream(device=dev, priority=pr)
 
     def make_prepared(self, device):
         return [dict(qkv=PreparedWeight([sp.q, sp.k, sp.v], device), o=PreparedWeight([sp.o], device),
@@ -377,11 +389,12 @@ class LayerStack(object):
         d[VL["VL_ST_TR_BLOCKS_FWD"]], d[VL["VL_ST_TR_BLOCKS_BWD"]] = self.tr_blocks
         d[VL["VL_ST_TR_BWD_LAYERS"]] = len(self.specs) - 1 if self.tr_bwd_layers is None else self.tr_bwd_layers
         d[VL["VL_ST_FUSE_IMAGES"]] = self.fuse_images
+        d[VL["VL_ST_DW_ROWMAJOR"]] = 1 if self.dw_rowmajor else 0
         side_ptr = None
         if ar.need_grad and self.overlap_dw:
             dev = ar.x32.device
             if self._side is None or self._side.device != dev:
-                self._side = torch.cuda.Stream(device=dev)
+                self._side = self._new_side_stream(dev)
             # (a forward whose backward never ran may still have its re-layout in flight on the side stream)
             torch.cuda.current_stream().wait_stream(self._side)
             side_ptr = self._side.cuda_stream
@@ -436,7 +449,7 @@ class LayerStack(object):
         side = None
         if self.overlap_dw:
             if self._side is None or self._side.device != dev:
-                self._side = torch.cuda.Stream(device=dev)
+                self._side = self._new_side_stream(dev)
             side = self._side
         side_ptr = side.cuda_stream if side is not None else None
         if self.layer_done_hook is None or not use_sink:

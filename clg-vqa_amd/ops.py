@@ -199,6 +199,22 @@ def dw_grouped(problems, K, accumulate=False):
                "vl_dw_grouped")
 
 
+def dw_grouped_rowmajor(problems, rows, accumulate=False):
+    """problems = [(dY [rows, >= M] bf16 view (row-major, ld = stride(0)), X [rows, >= N] bf16, out [M,N] fp32, mask or None,
+    M, N, colsum partials [ceil(N/256), M] fp32 or None)]: out (+)= dY[:, :M]^T . X[:, :N] from the row-major operands."""
+    import ctypes
+    n = len(problems)
+    arr = (ctypes.c_int64 * (10 * n))()
+    for i, (dy, x, out, mask, M, N, cs) in enumerate(problems):
+        pa, lda = _pld(dy)
+        pb, ldb = _pld(x)
+        assert out.dtype == torch.float32 and out.stride(1) == 1
+        arr[10 * i:10 * i + 10] = [pa, lda, pb, ldb, out.data_ptr(), out.stride(0), 0 if mask is None else _p(mask), M, N,
+                                   0 if cs is None else _p(cs)]
+    _lib.check(_lib.lib().vl_dw_grouped_rowmajor(ctypes.cast(arr, ctypes.c_void_p), n, rows, 1 if accumulate else 0,
+                                                 _stream()), "vl_dw_grouped_rowmajor")
+
+
 def attn2_fwd(qkv_hi, qkv_lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed, nq=None):
     _lib.check(_lib.lib().vl_attn2_fwd(_p(qkv_hi), _p(qkv_lo), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
                                        S if nq is None else nq, float(p_drop), int(seed), _stream()), "vl_attn2_fwd")

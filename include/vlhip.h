@@ -110,7 +110,14 @@ int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, int64_t max_b
 int vl_colsum_finalize(const float* partial, int64_t nblk, int64_t N, float* const* outs, int64_t nout, int accumulate,
                        void* stream);
 int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream);
-/* Up to 4 column reductions in one launch: `tab` = HOST array of n x VL_CR_FIELDS int64 {src [nrows, ncols] fp32, nrows,
+/* The same products straight from the ROW-MAJOR activations (no K-major images, no re-layout pass): problem fields
+ * {dY [rows, lda] at the problem's first column, lda, X [rows, ldb], ldb, out, ldo, mask (0 = none), M, N,
+ *  colsum partials (0 = none)}: out[M, N] (+)= dY[:, :M]^T . X[:, :N] (* mask).  MFMA fragments are gathered with
+ * transposing LDS reads (ds_read_b64_tr_b16).  colsum partials: fp32 [ceil(N / 256), M] -- row t holds the column sums of
+ * dY over the 64-row blocks kt = t (mod ceil(N / 256)); their sum (vl_colreduce_multi) is the bias gradient of the
+ * Linear, produced by the pass that reads dY anyway.  Needs rows % 64 == 0, M, N, lda, ldb multiples of 8. */
+int vl_dw_grouped_rowmajor(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, void* stream);
+/* Up to 8 column reductions in one launch: `tab` = HOST array of n x VL_CR_FIELDS int64 {src [nrows, ncols] fp32, nrows,
  * ncols, seg, out0, out1, out2, 0}: out_t[c] (+)= sum_rows src[row][t*seg + c] for the ncols / seg <= 3 segments (a
  * zero out_t skips a segment).  Deterministic.  Used per layer for the LayerNorm partials of vl_ln_bwd (dgamma, dbeta,
  * dbias) and the bias-gradient partials of vl_transpose_blocked. */
@@ -257,6 +264,8 @@ enum {
                                layer's own re-layout), the others at the end of forward (under the task head); 0 = all in forward */
   VL_ST_FUSE_IMAGES = 33, /* bit 0: the FFN1 epilogue writes the K-major image of the GELU output (VL_LY_T_H); bit 1: the GELU'
                              epilogue of FFN1's backward writes du's image + column sums (VL_LY_T_DU / VL_LY_CS_DU) */
+  VL_ST_DW_ROWMAJOR = 34, /* != 0: weight gradients straight from the row-major activations (vl_dw_grouped_rowmajor) whenever
+                             B*S (and B in the pooled-row mode) is a multiple of 64: no K-major images, no re-layout pass */
   VL_ST_FIELDS = 40
 };
 enum {

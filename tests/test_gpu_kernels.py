@@ -905,3 +905,52 @@ def test_gemm_epilogue_writes_the_kmajor_image_and_column_sums(M, N, K, tile):
     out = torch.empty(N, device=DEV)
     ops.colreduce_multi([(cs[:rows], N, (out,))])
     torch.testing.assert_close(out.double(), ref, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("K", [64, 448, 1024, 14336])
+def test_dw_grouped_rowmajor_matches_fp64_and_the_kmajor_path(K):
+    """The weight-gradient products straight from the ROW-MAJOR activations (transposing LDS reads): against fp64, against
+    the K-major path (same products, same k order inside a tile: bit-equal), with the packed [Q|K|V] gradient as three
+    column sub-ranges, an SFT mask, accumulation, ragged tile edges, and the bias column sums out of the same pass."""
+    H, I = 768, 3072
+    dqkv, dt1, du, dt2 = (_rand(K, n, seed=60 + i, scale=0.5).to(BF16) for i, n in enumerate((3 * H, H, I, H)))
+    x, ctx, x1, hh = (_rand(K, n, seed=70 + i).to(BF16) for i, n in enumerate((H, H, H, I)))
+    mask = (torch.rand(I, H, generator=torch.Generator().manual_seed(9)) < 0.6).float().to(DEV)
+    names = ("q", "k", "v", "o", "w1", "w2")
+    shapes = dict(q=(H, H), k=(H, H), v=(H, H), o=(H, H), w1=(I, H), w2=(H, I))
+    outs = {n: torch.full(shapes[n], float("nan"), device=DEV) for n in names}
+    cs = {n: torch.full(((shapes[n][1] + 255) // 256, shapes[n][0]), float("nan"), device=DEV) for n in ("q", "k", "v", "w1")}
+    probs = [(dqkv[:, :H], x, outs["q"], None, H, H, cs["q"]), (dqkv[:, H:2 * H], x, outs["k"], None, H, H, cs["k"]),
+             (dqkv[:, 2 * H:], x, outs["v"], None, H, H, cs["v"]), (dt1, ctx, outs["o"], None, H, H, None),
+             (du, x1, outs["w1"], mask, I, H, cs["w1"]), (dt2, hh, outs["w2"], None, H, I, None)]
+    ops.dw_grouped_rowmajor(probs, K)
+    refs = dict(q=dqkv[:, :H].double().t() @ x.double(), k=dqkv[:, H:2 * H].double().t() @ x.double(),
+                v=dqkv[:, 2 * H:].double().t() @ x.double(), o=dt1.double().t() @ ctx.double(),
+                w1=(du.double().t() @ x1.double()) * mask.double(), w2=dt2.double().t() @ hh.double())
+    tol = 3e-4 * math.sqrt(max(K, 256) / 256)
+    for n in names:
+        torch.testing.assert_close(outs[n].double(), refs[n], rtol=2e-5, atol=tol, msg=lambda m, n=n: "%s: %s" % (n, m))
+    bias_ref = dict(q=dqkv[:, :H], k=dqkv[:, H:2 * H], v=dqkv[:, 2 * H:], w1=du)
+    for n, c in cs.items():
+        torch.testing.assert_close(c.double().sum(0), bias_ref[n].double().sum(0), rtol=1e-5, atol=1e-3 * math.sqrt(K / 64))
+    # the K-major path adds the same products in the same order
+    mats = [dqkv, dt1, du, dt2, x, ctx, x1, hh]
+    imgs = [torch.empty(ops._lib.lib().vl_blocked_elems(K, m.shape[1]), dtype=BF16, device=DEV) for m in mats]
+    ops.transpose_blocked([(m, d, None) for m, d in zip(mats, imgs)], K)
+    Tqkv, Tt1, Tu, Tt2, Tx, Tctx, Tx1, Th = imgs
+    o2 = {n: torch.full(shapes[n], float("nan"), device=DEV) for n in names}
+    ops.dw_grouped([(Tqkv, 0, 3 * H, Tx, H, o2["q"], None, H, H), (Tqkv, H, 3 * H, Tx, H, o2["k"], None, H, H),
+                    (Tqkv, 2 * H, 3 * H, Tx, H, o2["v"], None, H, H), (Tt1, 0, H, Tctx, H, o2["o"], None, H, H),
+                    (Tu, 0, I, Tx1, H, o2["w1"], mask, I, H), (Tt2, 0, H, Th, I, o2["w2"], None, H, I)], K)
+    for n in names:
+        assert torch.equal(outs[n], o2[n]), n
+    first = {n: o.clone() for n, o in outs.items()}
+    ops.dw_grouped_rowmajor(probs, K, accumulate=True)
+    for n in names:
+        assert torch.equal(outs[n], first[n] + first[n]), n
+    odd_a, odd_b = _rand(K, 320, seed=80).to(BF16), _rand(K, 200, seed=81).to(BF16)  # ragged 256-tiles, N % 8 == 0
+    o3 = torch.full((320, 200), float("nan"), device=DEV)
+    c3 = torch.full((1, 320), float("nan"), device=DEV)
+    ops.dw_grouped_rowmajor([(odd_a, odd_b, o3, None, 320, 200, c3)], K)
+    torch.testing.assert_close(o3.double(), odd_a.double().t() @ odd_b.double(), rtol=2e-5, atol=tol)
+    torch.testing.assert_close(c3[0].double(), odd_a.double().sum(0), rtol=1e-5, atol=1e-3 * math.sqrt(K / 64))
