@@ -197,8 +197,10 @@ __device__ __forceinline__ float frag_sum(const bf16x8& f) {  // sum of the 8 bf
   return s;
 }
 
-template <bool TN>
+// MODE bit 0: the A operand (dY) is row-major (transposing reads), else its K-major image; bit 1: the same for B (X).
+template <int MODE>
 __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
+  constexpr bool TA = (MODE & 1) != 0, TB = (MODE & 2) != 0;
   constexpr int WC = 4;                        // wave grid 2 (M) x 4 (N)
   constexpr int MI = 4, NJ = 2;                // 16 x 16 MFMA tiles per quadrant
   constexpr int AH = 128, BH = 128;            // rows per half-tile
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const bool isB = x >= 2;
-      if (TN) {
+      if (isB ? TB : TA) {
         const int r = 4 * (wave + 8 * j) + (lane >> 4);  // row of the K-tile; unit = 4 rows x 256 B
         const int c = lane & 15;                         // physical 16-byte chunk of the row
         const int lb = (c >> 1) ^ ((r & 3) | (((r >> 3) & 1) << 2));  // logical 32-B block landing at physical c >> 1
@@ -273,55 +275,50 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 
   const int frow = lane & 15, fk = lane >> 4;
   int a_o[MI][2], b_o[NJ][2];
-  if (TN) {
+  {
     // transposed-read lane geometry: group fk owns rows 8 fk .. 8 fk + 7 of a 32-deep step; inside the group lane
     // 4 q + pp addresses row q, columns 4 pp .. 4 pp + 3 of the 4 x 16 block (the second read is 4 rows below)
     const int q = (lane & 15) >> 2, pp = lane & 3, hq = q | ((fk & 1) << 2);
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) a_o[i][kk] = (kk * 32 + 8 * fk + q) * 256 + (((wr * MI + i) ^ hq) << 5) + pp * 8;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) b_o[j][kk] = (kk * 32 + 8 * fk + q) * 256 + (((wc * NJ + j) ^ hq) << 5) + pp * 8;
-  } else {
-#pragma unroll
     for (int i = 0; i < MI; ++i) {
       const int row = wr * (MI * 16) + i * 16 + frow;
-      a_o[i][0] = row * 128 + ((fk ^ swz3(row)) << 4);
-      a_o[i][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        a_o[i][kk] = TA ? (kk * 32 + 8 * fk + q) * 256 + (((wr * MI + i) ^ hq) << 5) + pp * 8
+                        : row * 128 + (((4 * kk + fk) ^ swz3(row)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int row = wc * (NJ * 16) + j * 16 + frow;
-      b_o[j][0] = row * 128 + ((fk ^ swz3(row)) << 4);
-      b_o[j][1] = row * 128 + (((4 + fk) ^ swz3(row)) << 4);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+        b_o[j][kk] = TB ? (kk * 32 + 8 * fk + q) * 256 + (((wc * NJ + j) ^ hq) << 5) + pp * 8
+                        : row * 128 + (((4 * kk + fk) ^ swz3(row)) << 4);
     }
   }
-  float bsum[2][MI];  // TN: column sums of dY for this wave's output rows (bias gradient partials)
+  float bsum[2][MI];  // column sums of dY for this wave's output rows (bias gradient partials)
 #pragma unroll
   for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
     for (int i = 0; i < MI; ++i) bsum[qm][i] = 0.f;
-  const bool bias_wave = TN && P.cs != nullptr && wc == 0;
+  const bool bias_wave = P.cs != nullptr && wc == 0;
 
   bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
-#define DW_FRAG(ptr) (TN ? tr_frag(ptr) : *reinterpret_cast<const bf16x8*>(ptr))
+#define DW_FRAG(T, ptr) ((T) ? tr_frag(ptr) : *reinterpret_cast<const bf16x8*>(ptr))
 #define DW_READ_A(st, qm)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
-    fa[i][0] = DW_FRAG((st) + (qm) * OFF_A1 + a_o[i][0]);                                                        \
-    fa[i][1] = DW_FRAG((st) + (qm) * OFF_A1 + a_o[i][1]);                                                        \
+    fa[i][0] = DW_FRAG(TA, (st) + (qm) * OFF_A1 + a_o[i][0]);                                                        \
+    fa[i][1] = DW_FRAG(TA, (st) + (qm) * OFF_A1 + a_o[i][1]);                                                        \
   }
 #define DW_READ_B(st, qn, fb)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
-    fb[j][0] = DW_FRAG((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                                           \
-    fb[j][1] = DW_FRAG((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                                           \
+    fb[j][0] = DW_FRAG(TB, (st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                                           \
+    fb[j][1] = DW_FRAG(TB, (st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                                           \
   }
   // (after the MFMA section of a quadrant that consumed fresh A fragments: their column sums, on the selected K-tiles)
 #define DW_BIAS(qm)                                                                                              \
   do {                                                                                                           \
-    if (TN && bias_now) {                                                                                        \
+    if (bias_now) {                                                                                              \
       _Pragma("unroll") for (int i = 0; i < MI; ++i) bsum[qm][i] += frag_sum(fa[i][0]) + frag_sum(fa[i][1]);     \
     }                                                                                                            \
   } while (0)
@@ -384,7 +381,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 #undef DW_FRAG
 #undef DW_BIAS
 
-  if (TN && bias_wave) {  // rows 8 fk .. 8 fk + 7 of every 32-deep step were summed per lane group: add the 4 groups
+  if (bias_wave) {  // rows 8 fk .. 8 fk + 7 of every 32-deep step were summed per lane group: add the 4 groups
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -505,8 +502,10 @@ extern "C" int vl_colreduce_multi(const int64_t* tab, int64_t n, int accumulate,
 
 // probs: HOST array of nprob x VL_DW_FIELDS int64 {aT, a_rows_total, bT, b_rows_total, out, ldo, mask (0 = none), M, N, 0}
 // (rowmajor: {dY, lda, X, ldb, out, ldo, mask, M, N, colsum partials [ceil(N / 256), M] or 0})
-static int dw_launch(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, bool rowmajor, void* stream) {
+static int dw_launch(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, int mode, void* stream) {
+  const bool rowmajor = mode != 0;
   const char* fn = rowmajor ? "vl_dw_grouped_rowmajor" : "vl_dw_grouped";
+  VL_CHECK_ARG(mode >= 0 && mode <= 3, "%s: mode must be 0..3", fn);
   VL_CHECK_ARG(probs && nprob >= 1 && nprob <= MAXT && K >= 1, "%s: bad arguments", fn);
   VL_CHECK_ARG(!rowmajor || K % 64 == 0, "%s: the row count must be a multiple of 64 (got %lld)", fn, (long long)K);
   DwArgs a{};
@@ -515,39 +514,53 @@ static int dw_launch(const int64_t* probs, int64_t nprob, int64_t K, int accumul
   for (int i = 0; i < nprob; ++i) {
     const int64_t* t = probs + i * VL_DW_FIELDS;
     DwProb& p = a.p[i];
+    // per operand: row-major -> (pointer, leading dimension), K-major image -> (pointer, columns of the image); the
+    // distance between K-tiles is 64 * that number either way
     p.a = (const bf16_raw*)t[0]; p.ka = t[1] * 64; p.b = (const bf16_raw*)t[2]; p.kb = t[3] * 64;
     p.lda = t[1]; p.ldb = t[3];
     p.out = (float*)t[4]; p.ldo = t[5]; p.mask = (const float*)t[6]; p.M = (int)t[7]; p.N = (int)t[8];
-    p.cs = rowmajor ? (float*)t[9] : nullptr;
+    p.cs = (float*)t[9];
     VL_CHECK_ARG(p.a && p.b && p.out && p.M > 0 && p.N > 0 && t[1] >= p.M && t[3] >= p.N && p.ldo >= p.N,
                  "%s: problem %d: bad pointers / sizes", fn, i);
     VL_CHECK_ARG(al16(p.a) && al16(p.b) && al16(p.out) && al16(p.mask) && (p.ldo & 3) == 0,
                  "%s: problem %d: pointers must be 16-byte aligned, ldo a multiple of 4", fn, i);
-    VL_CHECK_ARG(!rowmajor || ((p.M & 7) == 0 && (p.N & 7) == 0 && p.M >= 8 && p.N >= 8 && (t[1] & 7) == 0 && (t[3] & 7) == 0),
-                 "%s: problem %d: M, N and the leading dimensions must be multiples of 8", fn, i);
+    VL_CHECK_ARG(!(mode & 1) || ((p.M & 7) == 0 && p.M >= 8 && (t[1] & 7) == 0),
+                 "%s: problem %d: M and lda must be multiples of 8 for a row-major dY", fn, i);
+    VL_CHECK_ARG(!(mode & 2) || ((p.N & 7) == 0 && p.N >= 8 && (t[3] & 7) == 0),
+                 "%s: problem %d: N and ldb must be multiples of 8 for a row-major X", fn, i);
     p.tile0 = tiles;
     p.tiles_n = (p.N + 255) / 256;
     tiles += ((p.M + 255) / 256) * p.tiles_n;
   }
   a.total_tiles = tiles;
   const size_t lds = 2 * 65536;
-  static bool attr_set[2] = {false, false};
-  const void* kfn = rowmajor ? reinterpret_cast<const void*>(&dw_grouped_kernel<true>)
-                             : reinterpret_cast<const void*>(&dw_grouped_kernel<false>);
-  if (!attr_set[rowmajor]) {
+  static bool attr_set[4] = {false, false, false, false};
+  const void* kfn = mode == 0   ? reinterpret_cast<const void*>(&dw_grouped_kernel<0>)
+                    : mode == 1 ? reinterpret_cast<const void*>(&dw_grouped_kernel<1>)
+                    : mode == 2 ? reinterpret_cast<const void*>(&dw_grouped_kernel<2>)
+                                : reinterpret_cast<const void*>(&dw_grouped_kernel<3>);
+  if (!attr_set[mode]) {
     hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vl_set_error(-3, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-    attr_set[rowmajor] = true;
+    attr_set[mode] = true;
   }
-  if (rowmajor) hipLaunchKernelGGL(dw_grouped_kernel<true>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(dw_grouped_kernel<false>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a);
+  switch (mode) {
+    case 0: hipLaunchKernelGGL(dw_grouped_kernel<0>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a); break;
+    case 1: hipLaunchKernelGGL(dw_grouped_kernel<1>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a); break;
+    case 2: hipLaunchKernelGGL(dw_grouped_kernel<2>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a); break;
+    default: hipLaunchKernelGGL(dw_grouped_kernel<3>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a); break;
+  }
   VL_CHECK_LAUNCH(fn);
   return 0;
 }
 
 extern "C" int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream) {
-  return dw_launch(probs, nprob, K, accumulate, false, stream);
+  return dw_launch(probs, nprob, K, accumulate, 0, stream);
 }
 extern "C" int vl_dw_grouped_rowmajor(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, void* stream) {
-  return dw_launch(probs, nprob, rows, accumulate, true, stream);
+  return dw_launch(probs, nprob, rows, accumulate, 3, stream);
+}
+// mode bit 0: dY row-major (else its K-major image: fields 0 / 1 = image, image columns), bit 1: the same for X
+extern "C" int vl_dw_grouped_mixed(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, int mode, void* stream) {
+  return dw_launch(probs, nprob, rows, accumulate, mode, stream);
 }

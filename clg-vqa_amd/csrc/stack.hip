@@ -73,11 +73,13 @@ int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, cons
 // The two [M, I] operands of the weight-gradient GEMMs -- GELU output h (X side of dW2) and du (dY side of dW1, + the
 // column sums that are b1's gradient) -- are written as K-major images by the epilogues of the GEMMs that produce them
 // when those run on the ping-pong kernel over whole 64-row blocks: half of the re-layout traffic never happens.
-// weight gradients from the row-major activations (no K-major images at all): whole 64-row blocks only
-bool dw_rowmajor(const int64_t* d) {
+// operand layouts of the weight-gradient GEMM (vl_dw_grouped_mixed): bit 0 = dY row-major, bit 1 = X row-major (no K-major
+// image, no re-layout pass for that side); whole 64-row blocks only, else 0 = both through the re-layout pass
+int dw_mode(const int64_t* d) {
   const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I];
-  return d[VL_ST_DW_ROWMAJOR] != 0 && (B * S) % 64 == 0 && (d[VL_ST_POOLED_ONLY] == 0 || B % 64 == 0) && H % 8 == 0 &&
-         I % 8 == 0 && d[VL_ST_CS_QKV] && d[VL_ST_CS_U];
+  const bool ok = (B * S) % 64 == 0 && (d[VL_ST_POOLED_ONLY] == 0 || B % 64 == 0) && H % 8 == 0 && I % 8 == 0 &&
+                  d[VL_ST_CS_QKV] && d[VL_ST_CS_U];
+  return ok ? (int)(d[VL_ST_DW_ROWMAJOR] & 3) : 0;
 }
 bool fused_shape(const int64_t* d, int64_t l) {
   const int64_t B = d[VL_ST_B], S = d[VL_ST_S], H = d[VL_ST_H], I = d[VL_ST_I], L = d[VL_ST_NLAYERS], M = B * S;
@@ -208,7 +210,7 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
   // layer's own re-layout.  History: written layer by layer beside the forward GEMMs the re-layout cost the QKV
   // projection +40 % (net zero); all 12 layers under the head was best while the head was ~75 eager launches (0.6 ms);
   // with the head as one native node (~0.3 ms) only the top layer's images still fit there (16.98 vs 17.28 ms / step).
-  if (layer_end == L && d[VL_ST_FIELDS + VL_LY_T_X] && !dw_rowmajor(d)) {
+  if (layer_end == L && d[VL_ST_FIELDS + VL_LY_T_X] && !(dw_mode(d) & 2)) {
     if (ss != (hipStream_t)stream) {
       VL_CHECK_ARG(fork, "vl_stack_fwd: a side stream needs the fork event of the descriptor");
       hipError_t e = hipEventRecord(fork, (hipStream_t)stream);
@@ -280,24 +282,45 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
                                   -1, nullptr, sm));
     // ---- optimizer-only work (side stream): weight-gradient GEMM + column sums ------------------------------------
     const int64_t nws = vl_ln_bwd_ws_floats(R, H) / (3 * H);
-    if (dw_rowmajor(d)) {
-      // straight from the row-major activations: one grouped launch, the bias column sums of dqkv / du ride in it
-      // (partials [3][.] per problem in the CS buffers), one column-reduction launch after it
+    if (const int mode = dw_mode(d)) {
+      // per side: row-major operand (transposing LDS reads in the GEMM) or its K-major image (one re-layout launch); the
+      // bias column sums of dqkv / du ride in the GEMM (partials [3][.] per problem in the CS buffers)
+      const bool dy_img = !(mode & 1), x_img = !(mode & 2);
+      if (x_img && l < d[VL_ST_TR_BWD_LAYERS]) VL_TRY(x_images(d, l, d[VL_ST_TR_BLOCKS_BWD], ss));
+      if (dy_img) {
+        const int64_t tr[4 * VL_TR_FIELDS] = {
+            y[VL_LY_DQKV], 3 * H, 3 * H, d[VL_ST_T_DQKV], 0, 0,
+            y[VL_LY_DT1], H, H, d[VL_ST_T_DT1], 0, 0,
+            y[VL_LY_DT2], H, H, d[VL_ST_T_DT2], 0, 0,
+            y[VL_LY_DU16], I, I, d[VL_ST_T_DU], 0, 0};
+        if (pooled) {
+          VL_TRY(vl_transpose_blocked(tr, 1, M, d[VL_ST_TR_BLOCKS_BWD], ss));
+          VL_TRY(vl_transpose_blocked(tr + VL_TR_FIELDS, 3, R, d[VL_ST_TR_BLOCKS_BWD], ss));
+        } else {
+          VL_TRY(vl_transpose_blocked(tr, 4, M, d[VL_ST_TR_BLOCKS_BWD], ss));
+        }
+      }
       const int64_t tq = (H + 255) / 256;  // partial rows of a problem whose X operand has H columns
       float* csq = ptr<float>(d[VL_ST_CS_QKV]);
       const int64_t cq = (int64_t)(uintptr_t)csq, ck = (int64_t)(uintptr_t)(csq + tq * H), cv = (int64_t)(uintptr_t)(csq + 2 * tq * H);
+      // dY operands {q, k, v, o, w1, w2} and X operands, each as (pointer, leading dimension | image columns)
+      const int64_t aq = dy_img ? d[VL_ST_T_DQKV] : y[VL_LY_DQKV], astep = dy_img ? 2 * 64 * H : 2 * H;
+      const int64_t a_o = dy_img ? d[VL_ST_T_DT1] : y[VL_LY_DT1], a_1 = dy_img ? d[VL_ST_T_DU] : y[VL_LY_DU16];
+      const int64_t a_2 = dy_img ? d[VL_ST_T_DT2] : y[VL_LY_DT2];
+      const int64_t bx = x_img ? y[VL_LY_T_X] : y[VL_LY_X_HI], bc = x_img ? y[VL_LY_T_CTX] : y[VL_LY_CTX_HI];
+      const int64_t b1 = x_img ? y[VL_LY_T_X1] : y[VL_LY_X1_HI], bh = x_img ? y[VL_LY_T_H] : y[VL_LY_H_HI];
       const int64_t pr[6 * VL_DW_FIELDS] = {
-          y[VL_LY_DQKV], 3 * H, y[VL_LY_X_HI], H, y[VL_LY_GRAD0 + 0], H, y[VL_LY_MASK0 + 0], H, H, cq,
-          y[VL_LY_DQKV] + 2 * H, 3 * H, y[VL_LY_X_HI], H, y[VL_LY_GRAD0 + 2], H, y[VL_LY_MASK0 + 1], H, H, ck,
-          y[VL_LY_DQKV] + 4 * H, 3 * H, y[VL_LY_X_HI], H, y[VL_LY_GRAD0 + 4], H, y[VL_LY_MASK0 + 2], H, H, cv,
-          y[VL_LY_DT1], H, y[VL_LY_CTX_HI], H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
-          y[VL_LY_DU16], I, y[VL_LY_X1_HI], H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, d[VL_ST_CS_U],
-          y[VL_LY_DT2], H, y[VL_LY_H_HI], I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
+          aq, 3 * H, bx, H, y[VL_LY_GRAD0 + 0], H, y[VL_LY_MASK0 + 0], H, H, cq,
+          aq + astep, 3 * H, bx, H, y[VL_LY_GRAD0 + 2], H, y[VL_LY_MASK0 + 1], H, H, ck,
+          aq + 2 * astep, 3 * H, bx, H, y[VL_LY_GRAD0 + 4], H, y[VL_LY_MASK0 + 2], H, H, cv,
+          a_o, H, bc, H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
+          a_1, I, b1, H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, d[VL_ST_CS_U],
+          a_2, H, bh, I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
       if (pooled) {  // Q/K/V gradients reduce over all M rows, the other three over the B live rows
-        VL_TRY(vl_dw_grouped_rowmajor(pr, 3, M, accumulate, ss));
-        VL_TRY(vl_dw_grouped_rowmajor(pr + 3 * VL_DW_FIELDS, 3, R, accumulate, ss));
+        VL_TRY(vl_dw_grouped_mixed(pr, 3, M, accumulate, mode, ss));
+        VL_TRY(vl_dw_grouped_mixed(pr + 3 * VL_DW_FIELDS, 3, R, accumulate, mode, ss));
       } else {
-        VL_TRY(vl_dw_grouped_rowmajor(pr, 6, M, accumulate, ss));
+        VL_TRY(vl_dw_grouped_mixed(pr, 6, M, accumulate, mode, ss));
       }
       const int64_t cr[6 * VL_CR_FIELDS] = {
           y[VL_LY_LNWS2], nws, 3 * H, H, y[VL_LY_GRAD0 + 14], y[VL_LY_GRAD0 + 15], y[VL_LY_GRAD0 + 13], 0,

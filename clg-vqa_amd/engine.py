@@ -122,29 +122,38 @@ def _src_ptrs(lin):
 
 
 def dw_gemm(dy16, x16, M, N, K, mask=None):
-    """dW[N,K] = dY[M,N]^T . X[M,K] (bf16 operands, fp32 out; optional SFT mask in the epilogue).  Feature sizes that
-    are multiples of 64 go through the K-major path of the layer stack (csrc/dw.hip); anything else (the 1842-label
-    classifier) through transposed copies + the split-K NT kernel."""
+    """dW[N,K] = dY[M,N]^T . X[M,K] (bf16 operands, fp32 out; optional SFT mask in the epilogue).  Whole 64-row blocks
+    with feature sizes that are multiples of 8 go straight from the row-major operands through the grouped ping-pong
+    kernel (csrc/dw.hip); feature sizes that are multiples of 64 through its K-major form (one re-layout launch);
+    anything else through transposed copies + the split-K NT kernel."""
     dev = dy16.device
     dW = torch.empty(N, K, dtype=torch.float32, device=dev)
+
+    def parts_for(tiles):
+        # few output tiles x many rows (the image-embedding Linear: 24 tiles x 9216 rows): split the rows over up to 8
+        # problems of one launch (fp32 slabs, summed in a fixed order) so that the grid covers the chip
+        nblk = M // 64
+        return max([s_ for s_ in range(1, 9) if M % 64 == 0 and nblk % s_ == 0 and tiles * s_ <= 256 and nblk // s_ >= 8]
+                   or [1])
+    tiles = ((N + 255) // 256) * ((K + 255) // 256)
+    if M % 64 == 0 and N % 8 == 0 and K % 8 == 0 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0:
+        # straight from the row-major operands (transposing LDS reads, csrc/dw.hip): no re-layout pass
+        parts = parts_for(tiles)
+        if parts == 1:
+            ops.dw_grouped_rowmajor([(dy16, x16, dW, mask, N, K, None)], M)
+            return dW
+        slabs = ops._tmp(torch.empty(parts, N * K, dtype=torch.float32, device=dev))
+        rows = M // parts
+        ops.dw_grouped_rowmajor([(dy16[i * rows:(i + 1) * rows], x16[i * rows:(i + 1) * rows], slabs[i].view(N, K), mask, N, K,
+                                  None) for i in range(parts)], rows)
+        ops.colreduce_multi([(slabs, N * K, (dW,))])
+        return dW
     if N % 64 == 0 and K % 64 == 0 and dy16.stride(0) % 8 == 0 and x16.stride(0) % 8 == 0:
         lib = _lib.lib()
         tA = ops._tmp(torch.empty(lib.vl_blocked_elems(M, N), dtype=BF16, device=dev))
         tB = ops._tmp(torch.empty(lib.vl_blocked_elems(M, K), dtype=BF16, device=dev))
         ops.transpose_blocked([(dy16, tA, None), (x16, tB, None)], M)
-        # few output tiles x many rows (the image-embedding Linear: 24 tiles x 9216 rows): split the rows over up to 8
-        # problems of one launch (fp32 slabs, summed in a fixed order) so that the grid covers the chip
-        tiles, nblk = ((N + 255) // 256) * ((K + 255) // 256), M // 64
-        parts = max([s_ for s_ in range(1, 9) if M % 64 == 0 and nblk % s_ == 0 and tiles * s_ <= 256 and nblk // s_ >= 8]
-                    or [1])
-        if parts == 1:
-            ops.dw_grouped([(tA, 0, N, tB, K, dW, mask, N, K)], M)
-            return dW
-        slabs = ops._tmp(torch.empty(parts, N * K, dtype=torch.float32, device=dev))
-        rows = M // parts
-        ops.dw_grouped([(tA[i * rows * N:], 0, N, tB[i * rows * K:], K, slabs[i].view(N, K), mask, N, K)
-                        for i in range(parts)], rows)
-        ops.colreduce_multi([(slabs, N * K, (dW,))])
+        ops.dw_grouped([(tA, 0, N, tB, K, dW, mask, N, K)], M)
         return dW
     if ops.gemm_tn_splitk(dy16, x16, N, K, M, dW):
         return dW if mask is None else ops.mask_mul(dW, mask, dW)
@@ -259,9 +268,10 @@ class LayerStack(object):
         self.specs, self.H, self.nh, self.I, self.eps = specs, H, nh, I, eps
         self.overlap_dw = True   # weight-gradient work on a second HIP stream (A/B knob)
         self.side_priority = None
-        # weight gradients straight from the row-major activations (transposing LDS reads in the dW GEMM) whenever B*S is
-        # a multiple of 64: no K-major images, no re-layout pass (False = the K-major path, also the fallback)
-        self.dw_rowmajor = True
+        # operand layouts of the weight-gradient GEMM whenever B*S is a multiple of 64 (bit 0: dY row-major, bit 1: X
+        # row-major -- transposing LDS reads instead of a K-major image written by a re-layout pass); 0 = both sides
+        # through the re-layout pass (also the fallback for ragged row counts)
+        self.dw_rowmajor = 3
         # the heads of this path read hidden_states[:, 0] only (BertTextPooler encoders.py:597-608, M3P BertPooler): the
         # last layer then runs on the B live rows after its K/V projection and the stack returns [B, 1, H] (exact: the
         # live rows are bit-identical to the dense run, the dead ones are never computed)
@@ -389,7 +399,7 @@ class LayerStack(object):
         d[VL["VL_ST_TR_BLOCKS_FWD"]], d[VL["VL_ST_TR_BLOCKS_BWD"]] = self.tr_blocks
         d[VL["VL_ST_TR_BWD_LAYERS"]] = len(self.specs) - 1 if self.tr_bwd_layers is None else self.tr_bwd_layers
         d[VL["VL_ST_FUSE_IMAGES"]] = self.fuse_images
-        d[VL["VL_ST_DW_ROWMAJOR"]] = 1 if self.dw_rowmajor else 0
+        d[VL["VL_ST_DW_ROWMAJOR"]] = int(self.dw_rowmajor)
         side_ptr = None
         if ar.need_grad and self.overlap_dw:
             dev = ar.x32.device

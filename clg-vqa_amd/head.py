@@ -8,9 +8,9 @@ The reference runs the head as ~30 eager kernels forward and ~45 backward on [ba
 latency (0.6 ms of an 18 ms step with nothing else on the chip).  Here it is ONE autograd node whose forward is 10
 launches and whose backward is 15: the three products go through the small-M GEMM path (csrc/gemm.hip), activation +
 dropout + operand split are one kernel per stage (csrc/head.hip), the last LayerNorm of the trunk hands over the (hi, lo)
-operand form of the pooled rows, and all three weight gradients + bias gradients are one re-layout launch, one
-column-reduction launch and one grouped GEMM launch (csrc/dw.hip).  Head weights are prepared by the engine's single
-per-step weight-preparation launch.
+operand form of the pooled rows, and all three weight gradients + bias gradients are one grouped GEMM launch straight
+from the row-major operands (csrc/dw.hip; the bias column sums ride in it) and one column-reduction launch.  Head
+weights are prepared by the engine's single per-step weight-preparation launch.
 
 No CPU fallback: module-by-module execution (``encoders.VLLinear`` etc., still native kernels) is only kept for feature
 sizes the fused kernels do not cover (not multiples of 64).
@@ -143,15 +143,26 @@ class HeadFunction(torch.autograd.Function):
             ops.act_bwd(ar.dy1, ar.z1, B, P, ctx.act, ctx.p, ctx.seed, dz16=ar.dz1_16)
             dx0 = f32(B, H)
             ops.gemm_nt(ar.dz1_16, None, pwp.t_hi, None, B, H, pwp.Np, 1, EPI_F32, out32=dx0)
-            # weight / bias gradients of the three Linears: one re-layout, one column reduction, one grouped GEMM
-            ops.transpose_blocked([(ar.dl16, ar.t_dl, ar.cs_dl), (ar.n_hi, ar.t_n, None), (ar.dz2_16, ar.t_dz2, ar.cs_dz2),
-                                   (ar.y1_hi, ar.t_y1, None), (ar.dz1_16, ar.t_dz1, ar.cs_dz1), (x_hi, ar.t_x, None)], B)
+            # weight / bias gradients of the three Linears
+            m2, m1, mp = (linear_params(l_)[1] for l_ in (head.fc2, head.fc1, head.pooler))
             db2p, db1, dbp = f32(NLp), f32(C), f32(P)
-            ops.colreduce_multi([(ar.cs_dl, NLp, (db2p,)), (ar.cs_dz2, C, (db1,)), (ar.cs_dz1, P, (dbp,))])
-            dW2, dW1, dWp = f32(NL, C), f32(C, P), f32(P, H)
-            ops.dw_grouped([(ar.t_dl, 0, NLp, ar.t_n, C, dW2, linear_params(head.fc2)[1], NL, C),
-                            (ar.t_dz2, 0, C, ar.t_y1, P, dW1, linear_params(head.fc1)[1], C, P),
-                            (ar.t_dz1, 0, P, ar.t_x, H, dWp, linear_params(head.pooler)[1], P, H)], B)
+            dW1, dWp = f32(C, P), f32(P, H)
+            if B % 64 == 0 and m2 is None:
+                # one grouped GEMM straight from the row-major operands, bias column sums in the same pass, one column
+                # reduction (d(logits) is zero-padded to NLp columns: the pad rows of dW2 / db2 are dropped)
+                dW2p = f32(NLp, C)
+                cs2, cs1, csp = f32((C + 255) // 256, NLp), f32((P + 255) // 256, C), f32((H + 255) // 256, P)
+                ops.dw_grouped_rowmajor([(ar.dl16, ar.n_hi, dW2p, None, NLp, C, cs2), (ar.dz2_16, ar.y1_hi, dW1, m1, C, P, cs1),
+                                         (ar.dz1_16, x_hi, dWp, mp, P, H, csp)], B)
+                ops.colreduce_multi([(cs2, NLp, (db2p,)), (cs1, C, (db1,)), (csp, P, (dbp,))])
+                dW2 = dW2p[:NL]
+            else:  # ragged batch: one re-layout, one column reduction, one grouped GEMM on the K-major images
+                ops.transpose_blocked([(ar.dl16, ar.t_dl, ar.cs_dl), (ar.n_hi, ar.t_n, None), (ar.dz2_16, ar.t_dz2, ar.cs_dz2),
+                                       (ar.y1_hi, ar.t_y1, None), (ar.dz1_16, ar.t_dz1, ar.cs_dz1), (x_hi, ar.t_x, None)], B)
+                ops.colreduce_multi([(ar.cs_dl, NLp, (db2p,)), (ar.cs_dz2, C, (db1,)), (ar.cs_dz1, P, (dbp,))])
+                dW2 = f32(NL, C)
+                ops.dw_grouped([(ar.t_dl, 0, NLp, ar.t_n, C, dW2, m2, NL, C), (ar.t_dz2, 0, C, ar.t_y1, P, dW1, m1, C, P),
+                                (ar.t_dz1, 0, P, ar.t_x, H, dWp, mp, P, H)], B)
         finally:
             ops.set_stream(None)
         ar.in_flight = False

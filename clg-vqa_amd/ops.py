@@ -215,6 +215,21 @@ def dw_grouped_rowmajor(problems, rows, accumulate=False):
                                                  _stream()), "vl_dw_grouped_rowmajor")
 
 
+def dw_grouped_mixed(problems, rows, mode, accumulate=False):
+    """problems = [(a, a_cols, b, b_cols, out, mask, M, N, colsum)]: an operand is a row-major 2-D bf16 view (its *_cols is
+    None) when its mode bit is set (bit 0: dY, bit 1: X), else its K-major image (1-D tensor) with the image's column count."""
+    import ctypes
+    n = len(problems)
+    arr = (ctypes.c_int64 * (10 * n))()
+    for i, (a, a_cols, b, b_cols, out, mask, M, N, cs) in enumerate(problems):
+        pa, lda = _pld(a) if mode & 1 else (_p(a), a_cols)
+        pb, ldb = _pld(b) if mode & 2 else (_p(b), b_cols)
+        arr[10 * i:10 * i + 10] = [pa, lda, pb, ldb, out.data_ptr(), out.stride(0), 0 if mask is None else _p(mask), M, N,
+                                   0 if cs is None else _p(cs)]
+    _lib.check(_lib.lib().vl_dw_grouped_mixed(ctypes.cast(arr, ctypes.c_void_p), n, rows, 1 if accumulate else 0, mode,
+                                              _stream()), "vl_dw_grouped_mixed")
+
+
 def attn2_fwd(qkv_hi, qkv_lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed, nq=None):
     _lib.check(_lib.lib().vl_attn2_fwd(_p(qkv_hi), _p(qkv_lo), _p(addmask), _p(ctx_hi), _p(ctx_lo), _p(lse), B, S, nh, dh,
                                        S if nq is None else nq, float(p_drop), int(seed), _stream()), "vl_attn2_fwd")

@@ -117,6 +117,11 @@ int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate
  * dY over the 64-row blocks kt = t (mod ceil(N / 256)); their sum (vl_colreduce_multi) is the bias gradient of the
  * Linear, produced by the pass that reads dY anyway.  Needs rows % 64 == 0, M, N, lda, ldb multiples of 8. */
 int vl_dw_grouped_rowmajor(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, void* stream);
+/* Per-operand layouts: mode bit 0 = dY row-major (fields 0 / 1 = pointer, lda), else its K-major image (image, image
+ * columns); bit 1 = the same for X (fields 2 / 3).  mode 0 = vl_dw_grouped, 3 = vl_dw_grouped_rowmajor; field 9 (colsum
+ * partials) works in every mode.  A transposing read moves half the bytes of a plain one per LDS instruction, so per
+ * K-tile and wave the fragment reads are 24 (mode 0), 32 (mode 2), 40 (mode 1), 48 (mode 3) instructions. */
+int vl_dw_grouped_mixed(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, int mode, void* stream);
 /* Up to 8 column reductions in one launch: `tab` = HOST array of n x VL_CR_FIELDS int64 {src [nrows, ncols] fp32, nrows,
  * ncols, seg, out0, out1, out2, 0}: out_t[c] (+)= sum_rows src[row][t*seg + c] for the ncols / seg <= 3 segments (a
  * zero out_t skips a segment).  Deterministic.  Used per layer for the LayerNorm partials of vl_ln_bwd (dgamma, dbeta,
@@ -264,8 +269,9 @@ enum {
                                layer's own re-layout), the others at the end of forward (under the task head); 0 = all in forward */
   VL_ST_FUSE_IMAGES = 33, /* bit 0: the FFN1 epilogue writes the K-major image of the GELU output (VL_LY_T_H); bit 1: the GELU'
                              epilogue of FFN1's backward writes du's image + column sums (VL_LY_T_DU / VL_LY_CS_DU) */
-  VL_ST_DW_ROWMAJOR = 34, /* != 0: weight gradients straight from the row-major activations (vl_dw_grouped_rowmajor) whenever
-                             B*S (and B in the pooled-row mode) is a multiple of 64: no K-major images, no re-layout pass */
+  VL_ST_DW_ROWMAJOR = 34, /* operand layouts of the weight-gradient GEMM (mode of vl_dw_grouped_mixed; bit 0: dY row-major,
+                             bit 1: X row-major -- no K-major image / re-layout pass for that side), used whenever B*S (and B
+                             in the pooled-row mode) is a multiple of 64; 0 = both sides through the re-layout pass */
   VL_ST_FIELDS = 40
 };
 enum {

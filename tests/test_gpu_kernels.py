@@ -944,6 +944,25 @@ def test_dw_grouped_rowmajor_matches_fp64_and_the_kmajor_path(K):
                     (Tu, 0, I, Tx1, H, o2["w1"], mask, I, H), (Tt2, 0, H, Th, I, o2["w2"], None, H, I)], K)
     for n in names:
         assert torch.equal(outs[n], o2[n]), n
+    # mixed layouts (one side row-major, the other its K-major image): the same sums again, bias partials included
+    for mode in (1, 2):
+        o3 = {n: torch.full(shapes[n], float("nan"), device=DEV) for n in names}
+        c3 = {n: torch.full_like(c, float("nan")) for n, c in cs.items()}
+        A = {n: (v[0], v[1]) for n, v in dict(q=(dqkv[:, :H], Tqkv), k=(dqkv[:, H:2 * H], Tqkv[64 * H:]),
+                                             v=(dqkv[:, 2 * H:], Tqkv[2 * 64 * H:]), o=(dt1, Tt1), w1=(du, Tu), w2=(dt2, Tt2)).items()}
+        Bm = dict(q=(x, Tx), k=(x, Tx), v=(x, Tx), o=(ctx, Tctx), w1=(x1, Tx1), w2=(hh, Th))
+        acols = dict(q=3 * H, k=3 * H, v=3 * H, o=H, w1=I, w2=H)
+        bcols = dict(q=H, k=H, v=H, o=H, w1=H, w2=I)
+        pm = []
+        for n in names:
+            a_t, a_ld = (A[n][0], None) if mode & 1 else (A[n][1], acols[n])
+            b_t, b_ld = (Bm[n][0], None) if mode & 2 else (Bm[n][1], bcols[n])
+            pm.append((a_t, a_ld, b_t, b_ld, o3[n], mask if n == "w1" else None, shapes[n][0], shapes[n][1], c3.get(n)))
+        ops.dw_grouped_mixed(pm, K, mode)
+        for n in names:
+            assert torch.equal(outs[n], o3[n]), (mode, n)
+        for n in cs:
+            assert torch.equal(cs[n], c3[n]), (mode, n)
     first = {n: o.clone() for n, o in outs.items()}
     ops.dw_grouped_rowmajor(probs, K, accumulate=True)
     for n in names:
