@@ -211,7 +211,7 @@ class StackArena(object):
       to a layer, the rest of the critical path shares one set;
     * scratch of the weight-gradient stream: the K-major images of the eight GEMM operands, column-sum partials."""
 
-    def __init__(self, L, B, S, H, I, nh, device, need_grad):
+    def __init__(self, L, B, S, H, I, nh, device, need_grad, images=True):
         self.key = (L, B, S, H, I, nh, str(device), need_grad)
         self.L, self.B, self.S, self.need_grad = L, B, S, need_grad
         M = B * S
@@ -242,14 +242,17 @@ class StackArena(object):
             self.dt2, self.du16, self.dt1, self.dqkv = b16(L, M, H), b16(L, M, I), b16(L, M, H), b16(L, M, 3 * H)
             nws = lib.vl_ln_bwd_ws_floats(M, H)
             self.lnws1, self.lnws2 = f32(L, nws), f32(L, nws)
-            img = lambda N: b16(lib.vl_blocked_elems(M, N))  # noqa: E731
-            self.t_dqkv, self.t_dt1, self.t_du, self.t_dt2 = img(3 * H), img(H), img(I), img(H)
-            # K-major images of the X operands: per layer, written during forward on the side stream
-            nx, ni = lib.vl_blocked_elems(M, H), lib.vl_blocked_elems(M, I)
-            self.t_x, self.t_ctx, self.t_x1, self.t_h = b16(L, nx), b16(L, nx), b16(L, nx), b16(L, ni)
-            # du's image + its column-sum partials per layer: written by the GELU' epilogue on the main stream while the
-            # side stream may still be reading the layer above's
-            self.t_du_l, self.cs_du_l = b16(L, ni), f32(L, 8 * ((M + 255) // 256), I)
+            # K-major images of the eight GEMM operands: only when the weight-gradient GEMM does not read the row-major
+            # activations directly (ragged row counts, A/B knobs)
+            self.images = images
+            if images:
+                img = lambda N: b16(lib.vl_blocked_elems(M, N))  # noqa: E731
+                self.t_dqkv, self.t_dt1, self.t_du, self.t_dt2 = img(3 * H), img(H), img(I), img(H)
+                nx, ni = lib.vl_blocked_elems(M, H), lib.vl_blocked_elems(M, I)
+                self.t_x, self.t_ctx, self.t_x1, self.t_h = b16(L, nx), b16(L, nx), b16(L, nx), b16(L, ni)
+                # du's image + its column-sum partials per layer (VL_ST_FUSE_IMAGES): written by the GELU' epilogue on
+                # the main stream while the side stream may still be reading the layer above's
+                self.t_du_l, self.cs_du_l = b16(L, ni), f32(L, 8 * ((M + 255) // 256), I)
             mb = (M + 63) // 64
             self.cs_qkv, self.cs_u = f32(mb, 3 * H), f32(mb, I)
             self.fork = torch.cuda.Event()
@@ -311,12 +314,14 @@ class LayerStack(object):
 
     # ---- buffers + descriptor -------------------------------------------------------------------------------------
     def arena(self, B, S, device, need_grad):
-        key = (B, S, str(device), need_grad)
+        # K-major operand images are only needed when the weight-gradient GEMM cannot read the row-major activations
+        rowmajor = int(self.dw_rowmajor) == 3 and (B * S) % 64 == 0 and (not self.pooled_only or B % 64 == 0)
+        key = (B, S, str(device), need_grad, rowmajor)
         lst = self._arenas.setdefault(key, [])
         for a in lst:
             if not a.in_flight:
                 return a
-        a = StackArena(len(self.specs), B, S, self.H, self.I, self.nh, device, need_grad)
+        a = StackArena(len(self.specs), B, S, self.H, self.I, self.nh, device, need_grad, images=not rowmajor)
         lst.append(a)
         if len(lst) > 4:
             raise RuntimeError("clg_vqa_amd: more than 4 training forwards without a backward on one model")
@@ -351,7 +356,8 @@ class LayerStack(object):
         if ar.need_grad:
             d[VL["VL_ST_EV_FORK"]] = ar.fork.cuda_event
             for k in ("t_dqkv", "t_dt1", "t_du", "t_dt2", "cs_qkv", "cs_u"):
-                d[VL["VL_ST_" + k.upper()]] = getattr(ar, k).data_ptr()
+                if ar.images or k.startswith("cs_"):
+                    d[VL["VL_ST_" + k.upper()]] = getattr(ar, k).data_ptr()
         it = iter(ptrs)
         for l in range(L):
             y = F + l * LF
@@ -378,9 +384,12 @@ class LayerStack(object):
                 put("DX", ar.dbuf[l % 2])
                 put("DY", ar.dbuf[(l + 1) % 2])  # (the top layer's DY is patched per backward)
                 put("DZ2", ar.dz2); put("DX1", ar.dx1); put("DZ1", ar.dz1); put("DCTX16", ar.dctx16)
-                for name in ("dt2", "du16", "dt1", "dqkv", "lnws1", "lnws2", "t_x", "t_ctx", "t_x1", "t_h"):
+                for name in ("dt2", "du16", "dt1", "dqkv", "lnws1", "lnws2"):
                     put(name.upper(), getattr(ar, name)[l])
-                put("T_DU", ar.t_du_l[l]); put("CS_DU", ar.cs_du_l[l])
+                if ar.images:
+                    for name in ("t_x", "t_ctx", "t_x1", "t_h"):
+                        put(name.upper(), getattr(ar, name)[l])
+                    put("T_DU", ar.t_du_l[l]); put("CS_DU", ar.cs_du_l[l])
         self._desc[id(ar)] = (fp, d)
         return d
 
