@@ -240,6 +240,8 @@ def main():
         model.engine.stack.tr_blocks = tuple(int(x) for x in os.environ["BENCH_TR_BLOCKS"].split(","))
     if os.environ.get("BENCH_DW_ROWMAJOR"):  # A/B: 0 = weight gradients through the K-major re-layout pass
         model.engine.stack.dw_rowmajor = int(os.environ["BENCH_DW_ROWMAJOR"])
+    if os.environ.get("BENCH_DX_TILE"):  # A/B: tile selection of the N = 768 single-pass products of backward
+        model.engine.stack.dx_tile = int(os.environ["BENCH_DX_TILE"])
     if os.environ.get("BENCH_FUSE_IMAGES"):  # A/B: K-major images by GEMM epilogues (bit 0: h, bit 1: du); 0 = re-layout
         model.engine.stack.fuse_images = int(os.environ["BENCH_FUSE_IMAGES"])
     if os.environ.get("BENCH_TR_BWD_LAYERS"):  # A/B: K-major X images of the bottom n layers written in backward

@@ -1234,9 +1234,10 @@ int launch_any(const GemmArgs& a, hipStream_t s, int splits = 1) {
     // M = 14336 they are 672 tiles = 2.6 rounds of 256x256 but exactly 3 full rounds of 224x256.
     const int64_t tm = (a.M + 255) / 256;
     const int64_t c256 = ((tm * ((a.N + 255) / 256) + 255) / 256) * 256, c192 = ((tm * ((a.N + 191) / 192) + 255) / 256) * 192;
-    // 1-pass products are the backward dX GEMMs, which share the chip with the dW GEMMs of the side stream: fewer,
-    // wider tiles win there even when they leave CUs to the other stream (A/B in situ: 22.9 vs 23.3 ms / step)
-    const bool wide = g_pingpong == 2 || (g_pingpong != 3 && (c256 <= c192 || (NSPLIT == 1 && g_pingpong == 1 && a.N >= 256)));
+    // (Round 1 forced the wide tile for the 1-pass products -- the backward dX GEMMs, which share the chip with the dW
+    // stream -- because it won beside the split-K dW kernels of that time; beside the long row-major dW GEMM that holds
+    // 108 CUs per layer the cost model's choice wins again: N = 768 as 224 tiles of 256 x 192, 16.92 vs 17.13 ms / step.)
+    const bool wide = g_pingpong == 2 || (g_pingpong != 3 && c256 <= c192);
     if constexpr ((NSPLIT == 3 && EPI == VL_EPI_GELU_SPLIT) || (NSPLIT == 1 && EPI == VL_EPI_DGELU_BF16)) {
       const int64_t c224 = (((a.M + 223) / 224) * ((a.N + 255) / 256) + 255) / 256 * 224;
       if (g_pingpong == 5 || (g_pingpong == 1 && wide && c224 < c256)) return launch3<NSPLIT, EPI, 2>(a, s);

@@ -120,8 +120,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
 // Backward.  A wave walks TWO rows per trip (rows r and r + rows_per_trip/2): the loads of both are issued before either
 // is reduced, i.e. 12 KB of loads in flight per wave instead of 6 -- the kernel is a latency-bound stream (one dependent
 // load -> two wave reductions -> store chain per row) and was running at 2.8 TB/s with one row per trip.
+#ifndef VL_LN_BWD_MINWG
+#define VL_LN_BWD_MINWG 1  // (A/B builds: workgroups per CU the register allocation must allow)
+#endif
 template <int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnArgs p) {
+__global__ __launch_bounds__(256, VL_LN_BWD_MINWG) void ln_bwd_kernel(LnArgs p) {
   __shared__ float red[3][4][NV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float invH = 1.0f / (float)p.H;

@@ -50,7 +50,7 @@ void prof_end(int64_t* pair, int64_t tag, int64_t flops, void* stream) {
 
 // vl_gemm_nt, optionally bracketed by a caller-owned event pair (descriptor field VL_ST_PROF); B-row products of the
 // pooled-row mode take the small-M path through the descriptor's workspace (VL_ST_SMALL_WS)
-struct GemmCtx { int64_t* prof; float* ws; int64_t ws_floats; };
+struct GemmCtx { int64_t* prof; float* ws; int64_t ws_floats; int64_t tile1; };
 struct GemmImage { void* img; int64_t cols; float* colsum; int64_t* colsum_rows; };
 int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
          int64_t M, int64_t N, int64_t K, int passes, int epi, const float* bias, const float* resid, float* out32,
@@ -58,6 +58,8 @@ int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, cons
   int64_t* pair = prof_begin(g.prof, stream);
   int64_t extra[VL_GX_FIELDS] = {0};
   extra[VL_GX_WS] = (int64_t)(uintptr_t)g.ws; extra[VL_GX_WS_FLOATS] = g.ws_floats;
+  // (VL_ST_DX_TILE, A/B knob: low byte = tile of the narrow single-pass products, next byte = of the wide one)
+  if (passes == 1 && g.tile1 && M >= 2048) extra[VL_GX_TILE] = N <= 1024 ? (g.tile1 & 255) : ((g.tile1 >> 8) & 255);
   if (im) {
     extra[VL_GX_IMG] = (int64_t)(uintptr_t)im->img; extra[VL_GX_IMG_COLS] = im->cols;
     extra[VL_GX_COLSUM] = (int64_t)(uintptr_t)im->colsum;
@@ -163,7 +165,7 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
   const float* addmask = ptr<const float>(d[VL_ST_ADDMASK]);
   const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
   int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
-  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS]};
+  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS], d[VL_ST_DX_TILE]};
   hipStream_t ss = stream_side ? (hipStream_t)stream_side : (hipStream_t)stream;
   hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);
   for (int64_t l = layer_begin; l < layer_end; ++l) {
@@ -235,7 +237,7 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
   const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
   const int accumulate = (int)d[VL_ST_ACCUMULATE];
   int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
-  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS]};
+  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS], d[VL_ST_DX_TILE]};
   hipStream_t sm = (hipStream_t)stream_main;
   hipStream_t ss = stream_side ? (hipStream_t)stream_side : sm;
   hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);

@@ -275,6 +275,7 @@ class LayerStack(object):
         # row-major -- transposing LDS reads instead of a K-major image written by a re-layout pass); 0 = both sides
         # through the re-layout pass (also the fallback for ragged row counts)
         self.dw_rowmajor = 3
+        self.dx_tile = 0  # tile selection of the narrow single-pass products of backward (0 = automatic; A/B knob)
         # the heads of this path read hidden_states[:, 0] only (BertTextPooler encoders.py:597-608, M3P BertPooler): the
         # last layer then runs on the B live rows after its K/V projection and the stack returns [B, 1, H] (exact: the
         # live rows are bit-identical to the dense run, the dead ones are never computed)
@@ -409,6 +410,7 @@ class LayerStack(object):
         d[VL["VL_ST_TR_BWD_LAYERS"]] = len(self.specs) - 1 if self.tr_bwd_layers is None else self.tr_bwd_layers
         d[VL["VL_ST_FUSE_IMAGES"]] = self.fuse_images
         d[VL["VL_ST_DW_ROWMAJOR"]] = int(self.dw_rowmajor)
+        d[VL["VL_ST_DX_TILE"]] = int(self.dx_tile)
         side_ptr = None
         if ar.need_grad and self.overlap_dw:
             dev = ar.x32.device

@@ -272,6 +272,8 @@ enum {
   VL_ST_DW_ROWMAJOR = 34, /* operand layouts of the weight-gradient GEMM (mode of vl_dw_grouped_mixed; bit 0: dY row-major,
                              bit 1: X row-major -- no K-major image / re-layout pass for that side), used whenever B*S (and B
                              in the pooled-row mode) is a multiple of 64; 0 = both sides through the re-layout pass */
+  VL_ST_DX_TILE = 35, /* tile selection (VL_GX_TILE) of the single-pass products of backward: low byte for N <= 1024, next byte
+                         for the wider ones; 0 = automatic */
   VL_ST_FIELDS = 40
 };
 enum {
