@@ -16,6 +16,8 @@
 // slabs, no reduce pass -- and written once, straight into the optimizer's gradient arena.  vl_dw_grouped runs all the
 // products of a layer as ONE launch (108 tiles of 256 x 256 at H = 768, I = 3072): it deliberately fills only part of
 // the chip, the rest stays with the backward critical path on the main stream.
+#include <type_traits>
+
 #include "common.h"
 #include "../../include/vlhip.h"
 
