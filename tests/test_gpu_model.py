@@ -345,3 +345,27 @@ def test_many_no_grad_forwards_reuse_one_inference_arena():
     l2 = model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])[0].sum()
     (l1 + l2).backward()
     assert model.bert.t_pooler.dense.weight.grad.abs().sum().item() > 0
+
+
+@pytest.mark.parametrize("B", [8, 64])
+def test_native_head_equals_the_module_by_module_head(B):
+    """head.py (one autograd node: small-M GEMMs, fused activation kernels, grouped weight gradients -- the row-major form
+    at B = 64, the K-major form at the ragged B = 8) against the module-by-module head (VLLinear / GeLU / BertLayerNorm,
+    torch dropout off): same logits to fp32 summation order, same gradients to bf16 operand rounding, incl. the trunk's."""
+    config = BertConfig.from_dict(uc2_cfg_dict(n_layers=2, vocab=600))
+    model, _ = _build(config, seed=31)
+    batch = make_batch(B, vocab_size=600, seed=77)
+    head = model._task_head("TASK15")
+    assert head.supported
+    res = {}
+    for native in (True, False):
+        head.supported = native
+        loss, _, logits = _run_native(model, batch, train_mode=False)
+        res[native] = (float(loss.detach()), logits.clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    head.supported = True
+    assert abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0])
+    torch.testing.assert_close(res[True][1], res[False][1], rtol=0, atol=5e-5)
+    assert set(res[True][2]) == set(res[False][2])
+    for n, g in res[False][2].items():
+        rel = (g.double() - res[True][2][n].double()).norm().item() / max(g.double().norm().item(), 1e-30)
+        assert rel <= 5e-3 or n.endswith("attention_self.key.bias"), (n, rel)
