@@ -142,3 +142,30 @@ def test_resume_uses_the_weights_only_loader(tmp_path):
     torch.save({"model_state_dict": {}, "tb_logger": argparse.Namespace(x=1)}, str(tmp_path / "ref.tar"))
     with pytest.raises(RuntimeError, match="weights-only"):
         train_utils.resume(str(tmp_path / "ref.tar"), lin, o, None, None)
+
+
+def test_task_head_selection_and_prepared_weight_wiring():
+    """host logic of the native task head (head.py): which feature sizes it takes, what it binds, and that the engine's
+    single weight-preparation table covers the head Linears; small-M workspace sizes of the C ABI (no compute)."""
+    from clg_vqa_amd.head import TaskHead
+    cfg = BertConfig.from_dict(uc2_cfg_dict(n_layers=2, vocab=300))
+    model = BertForVLTasks(cfg, TASK_CFG, ["TASK15"])
+    head = model._task_head("TASK15")
+    assert isinstance(head, TaskHead) and head.supported and head is model._task_head("TASK15")
+    assert (head.H, head.P, head.C, head.NL) == (cfg.hidden_size, cfg.pooler_size, cfg.clf_hidden_size, 1842)
+    assert head.act == cfg.fusion_act and [p.shape for p in head.params()] == [
+        model.bert.t_pooler.dense.weight.shape, model.bert.t_pooler.dense.bias.shape,
+        model.clfs_dict["TASK15"].logit_fc[0].weight.shape, model.clfs_dict["TASK15"].logit_fc[0].bias.shape,
+        model.clfs_dict["TASK15"].logit_fc[2].weight.shape, model.clfs_dict["TASK15"].logit_fc[2].bias.shape,
+        model.clfs_dict["TASK15"].logit_fc[3].weight.shape, model.clfs_dict["TASK15"].logit_fc[3].bias.shape]
+    lins = model.engine.head_linears()
+    assert lins == [model.bert.t_pooler.dense, model.clfs_dict["TASK15"].logit_fc[0], model.clfs_dict["TASK15"].logit_fc[3]]
+    odd = BertConfig.from_dict(dict(uc2_cfg_dict(n_layers=2, vocab=300), clf_hidden_size=200))
+    assert not BertForVLTasks(odd, TASK_CFG, ["TASK15"])._task_head("TASK15").supported  # module-by-module head instead
+    L = _lib.lib()
+    for (M, N, K) in ((256, 768, 3072), (256, 3072, 768), (256, 1842, 1536), (8, 1842, 128), (2048, 768, 768)):
+        w = L.vl_gemm_small_ws_floats(M, N, K)
+        assert w >= M * ((N + 3) // 4 * 4) and w % (M * ((N + 3) // 4 * 4)) == 0  # whole K-range slabs
+        assert w // (M * ((N + 3) // 4 * 4)) <= max(1, (K + 63) // 64)
+    assert L.vl_gemm_nt_path(14336, 768, 768, 3, 1) == 2 and L.vl_gemm_nt_path(256, 768, 3072, 3, 1) == 3
+    assert L.vl_gemm_nt_path(256, 768, 3072, 3, 0) == 2 and L.vl_gemm_nt_path(100, 96, 40, 1, 0) == 0
