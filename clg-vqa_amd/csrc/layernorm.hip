@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(LnReduceArgs a) {
 }
 
 #ifndef VL_LN_BWD_BLOCKS
-#define VL_LN_BWD_BLOCKS 512  // measured: 256..512 equal, 1024 +0.1 ms, 2048 +0.7 ms per step (partials traffic)
+#define VL_LN_BWD_BLOCKS 384  // measured beside the row-major dW GEMM (108 CUs busy on the side stream), ms / step, same box:
+                              // 192: 16.76, 256: 16.62, 320: 16.64, 384: 16.55, 512: 16.78, 768: 16.63, 1024 / 2048: worse (partials)
 #endif
 constexpr int LN_BWD_BLOCKS = VL_LN_BWD_BLOCKS;
 int nblk_for(int64_t M) {
