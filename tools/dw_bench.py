@@ -63,7 +63,8 @@ def per_problem():
         ta, tb = (torch.empty(L.vl_blocked_elems(K, t.shape[1]), dtype=BF16, device=DEV) for t in (a, b))
         ops.transpose_blocked([(a, ta, None), (b, tb, None)], K)
         res = []
-        for mode, pr in ((0, [(ta, na, tb, nb, out, None, Mo, No, None)]), (3, [(a, None, b, None, out, None, Mo, No, None)])):
+        for mode, pr in ((0, [(ta, na, tb, nb, out, None, Mo, No, None)]), (1, [(a, None, tb, nb, out, None, Mo, No, None)]),
+                         (2, [(ta, na, b, None, out, None, Mo, No, None)]), (3, [(a, None, b, None, out, None, Mo, No, None)])):
             ts = []
             for it in range(6):
                 filler.zero_()
@@ -75,7 +76,7 @@ def per_problem():
                 ts.append(e0.elapsed_time(e1) * 1e3)
             ts.sort()
             res.append(ts[len(ts) // 2])
-        print("dY width %4d, X width %4d (9 tiles): K-major %.0f us, row-major %.0f us" % (na, nb, *res), flush=True)
+        print("dY width %4d, X width %4d (9 tiles): modes 0 / 1 / 2 / 3: %.0f / %.0f / %.0f / %.0f us" % (na, nb, *res), flush=True)
 
 
 if __name__ == "__main__":
