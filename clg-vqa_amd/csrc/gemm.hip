@@ -25,7 +25,6 @@
 // bank-conflict free on the 64-bank LDS; the next tile's global loads are issued before the MFMA block
 // of the current one.  blockIdx is remapped so that the workgroups resident on one XCD (private L2)
 // walk neighbouring tiles of the same A row-panel.
-#include <cstdlib>
 #include <type_traits>
 
 // Only the explicit fmaf()s fuse: which a * b + c the optimizer contracts differs between the unrolled instances of an
@@ -65,7 +64,6 @@ struct GemmArgs {
   // row-major copy back; cs (ping-pong kernel only): fp32 column sums of the rounded out_hi values per (tile, M half,
   // wave row) -> cs[(tm * 2 + qm) * WR + wr][n], the bias-gradient partials the re-layout pass used to produce
   bf16_raw* img; long img_n; float* cs;
-  long a_kstride, b_kstride;    // elements between consecutive K-tiles of A / B (0 = the K-tile width: plain row-major)
 };
 
 __device__ __forceinline__ int lds_off(int row, int kc) { return row * 128 + ((kc ^ ((row >> 1) & 7)) << 4); }
@@ -514,13 +512,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
       src[x][j] = base + (long)g * (isB ? p.ldb : p.lda) + koff;
     }
   constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
-  const long kstr[2] = {p.a_kstride ? p.a_kstride : KSTEP, p.b_kstride ? p.b_kstride : KSTEP};
 #define G3_ISSUE(x, kt)                                                                                          \
   do {                                                                                                           \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][0] + (long)(kt) * kstr[(x) >> 1]),                       \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][0] + (long)(kt) * KSTEP),                                \
                                      (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + wave * 1024), 16, 0, 0);  \
     if (!(late && ((BSHORT && (x) >= 2) || (ASHORT && (x) == 1))))                                               \
-      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][1] + (long)(kt) * kstr[(x) >> 1]),                     \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][1] + (long)(kt) * KSTEP),                              \
                                        (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + (wave + 8) * 1024), 16, 0, 0); \
   } while (0)
   // wait until everything older than the youngest (nA A-half-tiles + nB B-half-tiles) has landed
@@ -1191,14 +1188,6 @@ int launch3(GemmArgs a, hipStream_t stream) {
   }
   a.tiles_m = (a.M + BMT - 1) / BMT;
   a.tiles_n = (a.N + BNT - 1) / BNT;
-#ifdef VL_EXPERIMENT_BLOCKED  // timing experiment only (wrong results): operands addressed as if stored [K / ks][rows][ks]
-  {
-    static const char* e = getenv("VL_BLOCKED");
-    const int ks = NSPLIT == 3 ? 32 : 64;
-    if (e && (e[0] == '1' || e[0] == '3')) { a.lda = ks; a.a_kstride = (long)a.M * ks; }
-    if (e && (e[0] == '2' || e[0] == '3')) { a.ldb = ks; a.b_kstride = (long)a.N * ks; }
-  }
-#endif
   tl_cs_rows = a.tiles_m * 2 * (CFG == 1 ? 4 : 2);  // column-sum partial rows this configuration writes
   hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
   VL_CHECK_LAUNCH("vl_gemm_nt(ping-pong)");
