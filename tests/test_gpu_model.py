@@ -286,8 +286,9 @@ def _pooled_vs_dense(B, T, V, train, bit_equal):
         if n.endswith("attention_self.key.bias"):
             continue
         assert rel <= (2e-6 if bit_equal else 5e-3)  # bf16 backward operands: an fp32 rounding flip becomes a bf16 one (measured 9e-4), (n, rel)
-    print("pooled vs dense (B=%d S=%d train=%s): loss equal, logits bit-equal, worst gradient rel diff %.2e at %s" % (
-        B, T + V, train, worst[0], worst[1]))
+    print("pooled vs dense (B=%d S=%d train=%s, %s): worst gradient rel diff %.2e at %s" % (
+        B, T + V, train, "same GEMM kernels: loss equal, logits bit-equal" if bit_equal else
+        "small-M path: max |dlogit| %.2e" % (res[False][1] - res[True][1]).abs().max().item(), worst[0], worst[1]))
 
 
 def test_training_mode_dropout_runs_and_is_seeded():
