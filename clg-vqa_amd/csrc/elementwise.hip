@@ -291,15 +291,36 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const int64_t* __rest
 }
 
 // ---- box-location projection (embeddings.py:661: Linear(num_locs -> H)) ---------------------------------------
-__global__ void loc_fwd_kernel(const float* __restrict__ loc, const float* __restrict__ w, const float* __restrict__ b,
-                               float* __restrict__ y, long R, int L, int H) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R * H) return;
-  const long r = i / H;
-  const int c = (int)(i - r * H);
-  float s = b[c];
-  for (int l = 0; l < L; ++l) s += loc[r * L + l] * w[c * L + l];
-  y[i] = s;
+// a thread owns 4 consecutive columns of 4 rows: the 4 x L weights of its columns are read once, every row costs L
+// broadcast loads and one 16-byte store (one thread per element with an integer division and a 28-byte-strided weight
+// walk ran at 0.7 TB/s: 42 us for the 28 MB of c2)
+__global__ __launch_bounds__(256) void loc_fwd_kernel(const float* __restrict__ loc, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float* __restrict__ y, long R, int L, int H) {
+  const int cq = H >> 2;                       // column quads per row (H % 4 == 0, checked by the host)
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const long rg = t / cq;                      // group of 4 rows
+  const int c = (int)(t - rg * cq) * 4;
+  if (rg * 4 >= R) return;
+  float wr[4][8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) wr[j][l] = l < L ? w[(c + j) * L + l] : 0.f;
+  const float4 bb = *reinterpret_cast<const float4*>(b + c);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long r = rg * 4 + i;
+    if (r >= R) break;
+    float x[8];
+#pragma unroll
+    for (int l = 0; l < 8; ++l) x[l] = l < L ? loc[r * L + l] : 0.f;
+    float o[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int l = 0; l < 8; ++l) o[j] += x[l] * wr[j][l];  // (same order of additions as the scalar form: l ascending)
+    *reinterpret_cast<float4*>(y + r * H + c) = make_float4(o[0], o[1], o[2], o[3]);
+  }
 }
 // dW[c][l] += sum_r dy[r][c] loc[r][l], db[c] += sum_r dy[r][c].  Workgroup = 64 rows x 64 columns: thread (tx = column, ty =
 // one of 4 row groups) walks 16 rows, the 4 groups are combined in LDS and 64 threads issue the atomics -- 12 x more
@@ -595,8 +616,10 @@ extern "C" int vl_embed_scatter_add(const int64_t* ids, const float* dz32, float
 
 extern "C" int vl_loc_linear_fwd(const float* loc, const float* w, const float* b, float* y32, int64_t R, int64_t L,
                                  int64_t H, void* stream) {
-  VL_CHECK_ARG(loc && w && b && y32 && R > 0 && L > 0 && L <= 8 && H > 0, "vl_loc_linear_fwd: bad arguments (L <= 8)");
-  hipLaunchKernelGGL(loc_fwd_kernel, dim3((unsigned)((R * H + 255) / 256)), dim3(256), 0, (hipStream_t)stream, loc, w,
+  VL_CHECK_ARG(loc && w && b && y32 && R > 0 && L > 0 && L <= 8 && H > 0 && (H & 3) == 0,
+               "vl_loc_linear_fwd: bad arguments (L <= 8, H a multiple of 4)");
+  const int64_t threads = ((R + 3) / 4) * (H / 4);
+  hipLaunchKernelGGL(loc_fwd_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, loc, w,
                      b, y32, (long)R, (int)L, (int)H);
   VL_CHECK_LAUNCH("vl_loc_linear_fwd");
   return 0;
