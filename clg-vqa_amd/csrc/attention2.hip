@@ -109,8 +109,16 @@ __device__ __forceinline__ void stage16(unsigned char* dst, const bf16_raw* src,
 // ---------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------
+// register budgets (workgroups per CU the allocation must allow), measured with tools/attn_bench.py: backward at S <= 128
+// gains 5 % from a third resident workgroup (197 -> 188 us at B = 256, S = 120), every other variant loses
+#ifndef VL_ATTN_FWD_MINWG
+#define VL_ATTN_FWD_MINWG(NT) 1
+#endif
+#ifndef VL_ATTN_BWD_MINWG
+#define VL_ATTN_BWD_MINWG(NT) ((NT) == 8 ? 3 : 1)
+#endif
 template <int NT, int DH>
-__global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
+__global__ __launch_bounds__(256, VL_ATTN_FWD_MINWG(NT)) void attn2_fwd_kernel(Attn2Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int Spad = NT * 16, NP = (NT + 1) / 2;  // key-tile pairs
   constexpr int KS = Geo<DH>::KS, DT = Geo<DH>::DT, PITCH = Geo<DH>::PITCH;
@@ -245,7 +253,7 @@ __global__ __launch_bounds__(256) void attn2_fwd_kernel(Attn2Args p) {
 // scores recomputed): dK and dV accumulate in registers over the query tiles.
 // ---------------------------------------------------------------------------------------------------------------
 template <int NT, int DH>
-__global__ __launch_bounds__(256) void attn2_bwd_kernel(Attn2Args p) {
+__global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(Attn2Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int Spad = NT * 16, NP = (NT + 1) / 2;
   constexpr int KS = Geo<DH>::KS, DT = Geo<DH>::DT, PITCH = Geo<DH>::PITCH;
