@@ -39,6 +39,17 @@ HBM_PEAK_GBS = 8000.0
 GFLOP_PER_SAMPLE = {"c2": 29.241, "c3": 29.241, "c4": 63.72, "c5": 63.71}  # SURVEY 8(d), training = 3 x forward
 
 
+def executed_gflop_per_sample(workload, model, S):
+    """SURVEY 8(d)'s algorithmic figure minus what the pooled-row mode of the last layer does not execute: for S - 1 of the
+    S rows of a sample the out-projection, the feed-forward block and the attention core (x 3: forward + backward)."""
+    stack = model.engine.stack
+    total = GFLOP_PER_SAMPLE[workload]
+    if not stack.pooled_only:
+        return total
+    H, I = stack.H, stack.I
+    return total - 3.0 * (S - 1) * (2.0 * H * H + 4.0 * H * I + 4.0 * S * H) * 1e-9
+
+
 class GemmTimer(object):
     """HIP-event pairs around GEMM launches of the native stack, on the stream they run on.  Every STRIDE-th launch of
     the timed region is bracketed (an event pair is a small bubble on the stream; timing all 84 GEMMs of a step made the
@@ -421,6 +432,7 @@ def main():
                        "precision": "forward GEMMs + attention 3-pass split bf16 MFMA (fp32-grade, logits within 1e-3); "
                                     "backward GEMMs + attention bf16 MFMA; fp32 residual stream / LN / optimizer",
                        "algorithmic_tflop_per_step": round(GFLOP_PER_SAMPLE[args.workload] * 1e-3 * world * args.batch, 3),
+                       "executed_tflop_per_step": round(executed_gflop_per_sample(args.workload, model, seq) * 1e-3 * world * args.batch, 3),
                        "final_loss": final_loss},
             "roofline": roof,
         }
