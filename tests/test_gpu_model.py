@@ -301,9 +301,13 @@ def test_training_mode_dropout_runs_and_is_seeded():
     model.engine.calls = 0
     l2, _, _ = _run_native(model, batch, train_mode=True)
     g2 = model.bert.encoder.layer[1].intermediate.dense.weight.grad.clone()
-    # pooled-output dropout is torch's (different stream each call) so compare the trunk only loosely:
-    assert torch.isfinite(l1) and torch.isfinite(l2)
-    assert torch.isfinite(g1).all() and g1.abs().sum().item() > 0
+    # every dropout mask of the step (embeddings, 12 x 3 sites of the stack, the pooled vector in the native head) is a
+    # function of (base seed, call count, site, element): the same call count gives the same step, bit for bit
+    assert torch.isfinite(l1) and torch.isfinite(g1).all() and g1.abs().sum().item() > 0
+    assert float(l1) == float(l2) and torch.equal(g1, g2)
+    model.engine.calls = 7
+    l3, _, _ = _run_native(model, batch, train_mode=True)
+    assert float(l3) != float(l1)  # another call count: other masks
     model.eval()
     le, _, _ = _run_native(model, batch, train_mode=False)
     assert abs(float(l1) - float(le)) > 1e-6  # dropout really was active
