@@ -374,3 +374,35 @@ def test_native_head_equals_the_module_by_module_head(B):
     for n, g in res[False][2].items():
         rel = (g.double() - res[True][2][n].double()).norm().item() / max(g.double().norm().item(), 1e-30)
         assert rel <= 5e-3 or n.endswith("attention_self.key.bias"), (n, rel)
+
+
+@pytest.mark.parametrize("B,pooled", [(64, True), (8, False)])
+def test_weight_gradient_layouts_and_image_producers_agree(B, pooled):
+    """The A/B knobs of the layer stack -- operand layouts of the weight-gradient GEMM (row-major / K-major per side), K-major
+    images by the GEMM epilogues, where the X images are written (end of forward / in backward) -- compute the same step:
+    weight gradients bit-equal (the same products in the same order), bias gradients to fp32 summation order."""
+    config = BertConfig.from_dict(uc2_cfg_dict(n_layers=2, vocab=600))
+    model, _ = _build(config, seed=41)
+    batch = make_batch(B, vocab_size=600, seed=90)
+    st = model.engine.stack
+    saved = (st.dw_rowmajor, st.fuse_images, st.tr_bwd_layers, st.pooled_only)
+    res = {}
+    try:
+        st.pooled_only = pooled
+        for key in ((3, 0, None), (0, 0, None), (0, 0, 0), (1, 0, None), (2, 0, 0), (0, 3, None), (0, 1, 0)):
+            st.dw_rowmajor, st.fuse_images, st.tr_bwd_layers = key
+            st._desc.clear()  # the descriptor caches the knobs' pointers
+            loss, _, _ = _run_native(model, batch, train_mode=False)
+            res[key] = (float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        st.dw_rowmajor, st.fuse_images, st.tr_bwd_layers, st.pooled_only = saved
+        st._desc.clear()
+    base = res[(3, 0, None)]
+    for key, (loss, grads) in res.items():
+        assert loss == base[0], key
+        for n, g in grads.items():
+            if g.dim() == 2 and ".encoder.layer." in n:
+                assert torch.equal(g, base[1][n]), (key, n)
+            else:
+                rel = (g.double() - base[1][n].double()).norm().item() / max(base[1][n].double().norm().item(), 1e-30)
+                assert rel <= 1e-5 or n.endswith("attention_self.key.bias"), (key, n, rel)
