@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   __shared__ float s_lr[ADAMW_MAX_SEG], s_wd[ADAMW_MAX_SEG];
   for (int i = threadIdx.x; i < nseg; i += 256) {
     s_end4[i] = (int)(seg_end[i] >> 2);
-    s_lr[i] = seg_lr[i] * lr_mult;
+    s_lr[i] = seg_lr[i] < 0.f ? -1.f : seg_lr[i] * lr_mult;
     s_wd[i] = seg_wd[i];
   }
   __syncthreads();
@@ -426,6 +426,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n4 - fl_len4; j += stride) {
     const long i = (row_flags && j >= fl_beg4) ? j + fl_len4 : j;
     const int sg = seg_of(i);
+    // a NEGATIVE segment learning rate marks a parameter that received no gradient: skipped entirely (no moment decay, no
+    // weight decay, no traffic), like `if p.grad is None: continue` in pytorch_transformers.AdamW -- M3P's 93 M never-used
+    // parameters are 2.6 GB per step otherwise
+    if (s_lr[sg] < 0.f) continue;
     update4(i, s_lr[sg], s_wd[sg]);
   }
   // flagged table, one wave per row: rows that never received a gradient have g = m = v = 0, so their AdamW update is
@@ -435,6 +439,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
   if (row_flags) {
     const int sg = seg_of(fl_beg4);
     const float lr = s_lr[sg], wd = s_wd[sg], decay = 1.f - lr * wd;
+    if (lr < 0.f) return;  // (the table itself received no gradient at all)
     const bool noop = !(wd > 0.f && lr != 0.f && decay != 1.0f);
     const int lane = threadIdx.x & 63;
     const long nrows = fl_len4 / fl_row4;

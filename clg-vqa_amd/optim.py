@@ -363,7 +363,7 @@ class FusedAdamW(object):
         if akey != self._active:
             self._active = akey
             self._active_list = active = tuple(h or (i == self._sink_index) for i, h in enumerate(has))
-            lr = [g[2] if act else 0.0 for g, act in zip(self.groups, active)]
+            lr = [g[2] if act else -1.0 for g, act in zip(self.groups, active)]  # negative = skipped by the kernel
             self.seg_lr.copy_(torch.tensor(lr, dtype=torch.float32))
         active = self._active_list
         eng = getattr(self.model, "engine", None)

@@ -468,6 +468,8 @@ int vl_gqa_loss(const float* logits, const float* target, const float* distances
  * row_flags (may be NULL): per-row "has ever received a gradient" bytes for the table occupying arena elements
  * [flag_begin, flag_begin + flag_rows*flag_row_len): rows with flag 0 have g = m = v = 0, so only p *= (1 - lr*wd)
  * is applied (8 B/param of traffic instead of 32; bit-identical to the dense update).
+ * A NEGATIVE seg_lr marks a segment whose parameter received no gradient: it is skipped entirely (no moment decay, no
+ * weight decay, no memory traffic), like `if p.grad is None: continue` in pytorch_transformers.AdamW.
  * ------------------------------------------------------------------------------------------------------------ */
 int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const int64_t* seg_end,
              const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1, float beta2, float eps,

@@ -414,6 +414,16 @@ def test_adamw_and_sumsq():
         rp = rp - ss * rm / (rv.sqrt() + eps)
         rp = rp - lr * lr_mult * wd * rp
     torch.testing.assert_close(p.double().cpu(), rp, rtol=1e-5, atol=1e-7)
+    # a negative segment learning rate = "this parameter received no gradient": p, m, v (and g) of the segment are not
+    # touched at all (pytorch_transformers.AdamW: `if p.grad is None: continue`), the others update as before
+    ps, ms, vs, gs_ = p.clone(), m.clone(), v.clone(), g.clone()
+    ops.adamw(p, g, m, v, seg_end, torch.tensor([4e-5, -1.0, 4e-5], device=DEV), seg_wd, b1, b2, eps, 4, True, lr_mult, None, gs,
+              True)
+    for t, t0 in ((p, ps), (m, ms), (v, vs), (g, gs_)):
+        assert torch.equal(t[1000:1004], t0[1000:1004])
+    assert not torch.equal(p[:1000], ps[:1000]) and not torch.equal(m[1004:], ms[1004:])
+    assert (g[:1000] == 0).all() and (g[1004:] == 0).all()  # zero_grad on the active segments
+    g.copy_(gs_)
     out = torch.zeros(1, device=DEV)
     ops.sumsq(g, out)
     torch.testing.assert_close(out.double().cpu(), (g0 * g0).sum().view(1), rtol=1e-5, atol=1e-5)
