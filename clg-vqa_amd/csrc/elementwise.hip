@@ -54,6 +54,40 @@ __global__ void split_kernel(const float* __restrict__ x, bf16_raw* __restrict__
 __device__ __forceinline__ void weight_prep_tile(const float* __restrict__ w, const float* __restrict__ mask,
                                                  bf16_raw* w_hi, bf16_raw* w_lo, bf16_raw* wt_hi, int N, int K,
                                                  long ldw, long ldt, int n0, int k0, bf16_raw (*tile)[66]) {
+  // fast path (whole tile inside the matrix, 16-byte-aligned rows): 16-byte loads, 8-byte stores, 4 elements per thread
+  // and pass; the scalar path below serves ragged edges (the 1842-label classifier) and odd leading dimensions
+  const bool vec = n0 + 64 <= N && k0 + 64 <= K && (K & 3) == 0 && (ldw & 3) == 0 && (ldt & 3) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(w) | reinterpret_cast<uintptr_t>(mask)) & 15) == 0 &&
+                   ((reinterpret_cast<uintptr_t>(w_hi) | reinterpret_cast<uintptr_t>(w_lo) | reinterpret_cast<uintptr_t>(wt_hi)) & 7) == 0;
+  if (vec) {
+    const int c4 = (threadIdx.x & 15) * 4, r = threadIdx.x >> 4;  // 16 threads per row, 16 rows per pass
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int rr = pass * 16 + r;
+      const long src = (long)(n0 + rr) * K + k0 + c4;
+      float4 v = *reinterpret_cast<const float4*>(w + src);
+      if (mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(mask + src);
+        v.x *= mk.x; v.y *= mk.y; v.z *= mk.z; v.w *= mk.w;
+      }
+      ushort4 h, l;
+      split_bf16(v.x, h.x, l.x); split_bf16(v.y, h.y, l.y); split_bf16(v.z, h.z, l.z); split_bf16(v.w, h.w, l.w);
+      const long dst = (long)(n0 + rr) * ldw + k0 + c4;
+      if (w_hi) *reinterpret_cast<ushort4*>(w_hi + dst) = h;
+      if (w_lo) *reinterpret_cast<ushort4*>(w_lo + dst) = l;
+      tile[rr][c4] = h.x; tile[rr][c4 + 1] = h.y; tile[rr][c4 + 2] = h.z; tile[rr][c4 + 3] = h.w;
+    }
+    if (!wt_hi) return;
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int kk = pass * 16 + r;  // row of the transposed tile
+      ushort4 t;
+      t.x = tile[c4][kk]; t.y = tile[c4 + 1][kk]; t.z = tile[c4 + 2][kk]; t.w = tile[c4 + 3][kk];
+      *reinterpret_cast<ushort4*>(wt_hi + (long)(k0 + kk) * ldt + n0 + c4) = t;
+    }
+    return;
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int rr = ty; rr < 64; rr += 4) {
     const int n = n0 + rr, k = k0 + tx;
