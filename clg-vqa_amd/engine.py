@@ -576,7 +576,7 @@ class EngineBase(object):
         explicit = self._dirty  # set by the optimizer every step: no need to fingerprint versions to find that out
         if explicit or any(p._key() != p.key for p in all_pw):
             # the device table only depends on where the source weights / masks live: compare those pointers first
-            ident = tuple(q for p in all_pw for l in p.linears for q in _src_ptrs(l))
+            ident = tuple(q for p in all_pw for l in p.linears for q in _src_ptrs(l) + (l.bias.data_ptr(),))
             if pw.get("table_ident") != ident:
                 rows, tile0 = [], 0
                 for r in (r for p in all_pw for r in p.descriptors()):
@@ -584,10 +584,14 @@ class EngineBase(object):
                     tile0 += ((r[5] + 63) // 64) * ((r[6] + 63) // 64)
                 pw["table"] = torch.tensor(rows, dtype=torch.int64).to(device)
                 pw["table_ident"], pw["table_tiles"] = ident, tile0
+                # the packed [Q|K|V] bias copies of all layers: (destination views, source biases) built once per
+                # parameter placement -- ~150 tensor slices / detaches per step otherwise, on the host's critical path
+                # at the step boundary
+                pairs = [pr for p in all_pw for pr in p.bias_pairs()]
+                pw["bias_dst"], pw["bias_src"] = [d for d, _ in pairs], [s_ for _, s_ in pairs]
             ops.weight_prep_multi(pw["table"], pw["table"].shape[0], pw["table_tiles"])  # one launch per step
-            pairs = [pr for p in all_pw for pr in p.bias_pairs()]
-            if pairs:  # the packed [Q|K|V] biases of all layers: one multi-tensor copy
-                torch._foreach_copy_([d for d, _ in pairs], [s_ for _, s_ in pairs])
+            if pw["bias_dst"]:  # one multi-tensor copy
+                torch._foreach_copy_(pw["bias_dst"], pw["bias_src"])
             for p in all_pw:
                 p.refresh_bias(fingerprint=not explicit, pack=False)
         self._dirty = False
