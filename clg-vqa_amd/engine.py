@@ -309,6 +309,11 @@ class LayerStack(object):
             pr = max(torch.cuda.Stream.priority_range())
         return torch.cuda.Stream(device=dev, priority=pr)
 
+    def side_stream(self, dev):
+        if self._side is None or self._side.device != dev:
+            self._side = self._new_side_stream(dev)
+        return self._side
+
     def make_prepared(self, device):
         return [dict(qkv=PreparedWeight([sp.q, sp.k, sp.v], device), o=PreparedWeight([sp.o], device),
                      w1=PreparedWeight([sp.w1], device), w2=PreparedWeight([sp.w2], device)) for sp in self.specs]
@@ -607,6 +612,7 @@ class UC2Engine(EngineBase):
         self.H, self.nh, self.I, self.eps = cfg.hidden_size, cfg.num_attention_heads, cfg.intermediate_size, cfg.layer_norm_eps
         self.n_layers = len(model.bert.encoder.layer) // 2
         self._init_common(self.H, self.nh)
+        self.embed_overlap = True  # token / box-location embeddings on the side stream beside the feature projection
         specs = []
         for l in range(self.n_layers):
             at = model.bert.encoder.layer[2 * l]
@@ -667,29 +673,40 @@ class UC2Engine(EngineBase):
         sv = dict(B=B, T=T, V=V, F=F, L=L, S=S, p_hid=p_hid, p_att=p_att, seed=seed, seed0=seed0, ids=ids, seg=seg,
                   locs=locs2, pw=pw, arena=ar)
 
+        # the embeddings are ~10 small launches: the token rows and the box-location rows (no GEMM) run on the side stream
+        # beside the region-feature projection (split + GEMM + LayerNorm) of the main stream
+        main = torch.cuda.current_stream()
+        side = self.stack.side_stream(dev) if self.embed_overlap else None
+        x32, x_hi, x_lo = self.stack.input_buffers(ar)
+        type_w = emb.new_token_type_embeddings.weight.detach()
+        z_t, mean_t, rstd_t = f32(BT, H), f32(BT), f32(BT)
+        z_l, mean_l, rstd_l, b32 = f32(BV, H), f32(BV), f32(BV), f32(BV, H)
+        if side is not None:
+            side.wait_stream(main)  # parameters (optimizer), batch tensors, buffers of the previous step
+            ops.set_stream(side.cuda_stream)
         am = ar.addmask
         ops.addmask(tmask, imask, am, B, T, V)
-
-        x32, x_hi, x_lo = self.stack.input_buffers(ar)
         # text rows: word + position + type -> LN -> dropout   (embeddings.py:648-655)
-        z_t, mean_t, rstd_t = f32(BT, H), f32(BT), f32(BT)
-        type_w = emb.new_token_type_embeddings.weight.detach()
         ops.embed_text_fwd(ids, seg, emb.word_embeddings.weight.detach(), emb.position_embeddings.weight.detach(),
                            type_w, z_t, B, T, H, int(cfg.pad_token_id))
         ops.ln_fwd(z_t, None, None, emb.LayerNorm.weight.detach(), emb.LayerNorm.bias.detach(), self.eps, x32, x_hi,
                    x_lo, mean_t, rstd_t, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
-        # box rows: LN(feat W^T + b) + LN(loc W^T + b) + type[1] -> LN -> dropout   (embeddings.py:660-667)
+        # box locations: LN(loc W^T + b)   (embeddings.py:661-664)
+        ops.loc_linear_fwd(locs2, emb.image_location_embeddings.weight.detach(),
+                           emb.image_location_embeddings.bias.detach(), z_l, BV, L, H)
+        ops.ln_fwd(z_l, None, None, emb.image_location_layer_norm.weight.detach(),
+                   emb.image_location_layer_norm.bias.detach(), self.eps, b32, None, None, mean_l, rstd_l, BV, H)
+        if side is not None:
+            ops.set_stream(main.cuda_stream)
+        # box rows: LN(feat W^T + b) + LN(loc ...) + type[1] -> LN -> dropout   (embeddings.py:660-667)
         f_hi, f_lo = b16(BV, F), b16(BV, F)
         ops.split_f32(feats2, f_hi, f_lo)
         z_i, mean_i, rstd_i, a32 = f32(BV, H), f32(BV), f32(BV), f32(BV, H)
         ops.gemm_nt(f_hi, f_lo, pw["img"].hi, pw["img"].lo, BV, H, F, 3, EPI_F32, bias=pw["img"].bias, out32=z_i)
         ops.ln_fwd(z_i, None, None, emb.image_layer_norm.weight.detach(), emb.image_layer_norm.bias.detach(),
                    self.eps, a32, None, None, mean_i, rstd_i, BV, H)
-        z_l, mean_l, rstd_l, b32 = f32(BV, H), f32(BV), f32(BV), f32(BV, H)
-        ops.loc_linear_fwd(locs2, emb.image_location_embeddings.weight.detach(),
-                           emb.image_location_embeddings.bias.detach(), z_l, BV, L, H)
-        ops.ln_fwd(z_l, None, None, emb.image_location_layer_norm.weight.detach(),
-                   emb.image_location_layer_norm.bias.detach(), self.eps, b32, None, None, mean_l, rstd_l, BV, H)
+        if side is not None:
+            main.wait_stream(side)
         mean_v, rstd_v = f32(BV), f32(BV)
         ops.ln_fwd(a32, b32, type_w[1], emb.v_LayerNorm.weight.detach(), emb.v_LayerNorm.bias.detach(), self.eps,
                    x32, x_hi, x_lo, mean_v, rstd_v, BV, H, group=V, out_stride=S, out_off=T, p_post=p_hid,
