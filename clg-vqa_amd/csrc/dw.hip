@@ -182,13 +182,26 @@ __device__ __forceinline__ int swz3(int row) {
 // Bias gradients (column sums of dY over the rows) come out of the same pass: the waves with wc == 0 add up the A
 // fragments they hold anyway (VALU, in the load section) for the K-tiles kt = tn (mod tiles_n) of their tile row, so the
 // tiles of a row share the work; partial row tn of cs is summed by vl_colreduce_multi.
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* p0) {
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0 + 4 * 256));
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+// The reads are inline assembly on purpose: the compiler puts s_waitcnt vmcnt(0) in front of the
+// __builtin_amdgcn_ds_read_tr16_b64 intrinsic whenever LDS-DMA loads are outstanding (it cannot prove the read does not
+// alias them), which drains the whole prefetch pipeline before every fragment section -- measured 515 us instead of
+// 330 us for one layer's six problems.  The counted vmcnt waits + barriers of the loop are what orders DMA and reads;
+// the results are complete after the s_waitcnt lgkmcnt(0) that opens every MFMA section.
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+template <int OFF>
+__device__ __forceinline__ bf16x8 tr_frag(unsigned lds_addr) {
+  static_assert(OFF >= 0 && OFF + 4 * 256 < 65536, "LDS offset field");
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  u32x2 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(lds_addr), "n"(OFF));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds_addr), "n"(OFF + 4 * 256));
+  const u32x4 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
   return __builtin_bit_cast(bf16x8, v);
+}
+template <bool T, int OFF>
+__device__ __forceinline__ bf16x8 dw_frag(const unsigned char* st, unsigned st_lds, int o) {
+  if constexpr (T) return tr_frag<OFF>(st_lds + (unsigned)o);
+  else return *reinterpret_cast<const bf16x8*>(st + OFF + o);
 }
 __device__ __forceinline__ float frag_sum(const bf16x8& f) {  // sum of the 8 bf16 values (fp32)
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -276,6 +289,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
         for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15, fk = lane >> 4;
+  const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   int a_o[MI][2], b_o[NJ][2];
   {
     // transposed-read lane geometry: group fk owns rows 8 fk .. 8 fk + 7 of a 32-deep step; inside the group lane
@@ -306,16 +320,15 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   const bool bias_wave = P.cs != nullptr && wc == 0;
 
   bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
-#define DW_FRAG(T, ptr) ((T) ? tr_frag(ptr) : *reinterpret_cast<const bf16x8*>(ptr))
 #define DW_READ_A(st, qm)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
-    fa[i][0] = DW_FRAG(TA, (st) + (qm) * OFF_A1 + a_o[i][0]);                                                        \
-    fa[i][1] = DW_FRAG(TA, (st) + (qm) * OFF_A1 + a_o[i][1]);                                                        \
+    fa[i][0] = dw_frag<TA, (qm) * OFF_A1>(st, st_lds, a_o[i][0]);                                                \
+    fa[i][1] = dw_frag<TA, (qm) * OFF_A1>(st, st_lds, a_o[i][1]);                                                \
   }
 #define DW_READ_B(st, qn, fb)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
-    fb[j][0] = DW_FRAG(TB, (st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                                           \
-    fb[j][1] = DW_FRAG(TB, (st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                                           \
+    fb[j][0] = dw_frag<TB, OFF_B0 + (qn) * (BH * 128)>(st, st_lds, b_o[j][0]);                                   \
+    fb[j][1] = dw_frag<TB, OFF_B0 + (qn) * (BH * 128)>(st, st_lds, b_o[j][1]);                                   \
   }
   // (after the MFMA section of a quadrant that consumed fresh A fragments: their column sums, on the selected K-tiles)
 #define DW_BIAS(qm)                                                                                              \
@@ -352,6 +365,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
+    const unsigned st_lds = smem_lds + (kt & 1) * STAGE;
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
     const bool bias_now = bias_wave && (kt % P.tiles_n) == tn;
     DW_READ_B(st, 0, fb0);
@@ -380,7 +394,6 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 #undef DW_READ_A
 #undef DW_READ_B
 #undef DW_MFMA
-#undef DW_FRAG
 #undef DW_BIAS
 
   if (bias_wave) {  // rows 8 fk .. 8 fk + 7 of every 32-deep step were summed per lane group: add the 4 groups

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the weight-gradient GEMM forms on one layer's six problems at c2 (rows = 14336): K-major (mode 0),
 row-major 8-wave ping-pong (mode 3); `per`: one 9-tile problem per operand width.  Usage (GPU box): python3 tools/dw_bench.py"""
+import os
 import sys
 
 import torch
@@ -24,6 +25,8 @@ def main():
     rm = [(dqkv[:, :H], None, x, None, outs["q"], None, H, H, cs["q"]), (dqkv[:, H:2 * H], None, x, None, outs["k"], None, H, H, cs["k"]),
           (dqkv[:, 2 * H:], None, x, None, outs["v"], None, H, H, cs["v"]), (dt1, None, ctx, None, outs["o"], None, H, H, None),
           (du, None, x1, None, outs["w1"], None, I, H, cs["w1"]), (dt2, None, hh, None, outs["w2"], None, H, I, None)]
+    if os.environ.get("NOCS"):
+        rm = [t[:8] + (None,) for t in rm]
     L = _lib.lib()
     mats = [dqkv, dt1, du, dt2, x, ctx, x1, hh]
     imgs = [torch.empty(L.vl_blocked_elems(K, m.shape[1]), dtype=BF16, device=DEV) for m in mats]
