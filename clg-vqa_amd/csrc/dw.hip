@@ -180,8 +180,8 @@ __device__ __forceinline__ int swz3(int row) {
 // XOR-swizzled with h(row) = (row & 3) | ((row >> 3) & 1) << 2 on the DMA source address and undone by the reads: the 8
 // rows a 32-lane half touches hit 8 different 32-byte bank groups.  Needs rows % 64 == 0 and M, N multiples of 8.
 // Bias gradients (column sums of dY over the rows) come out of the same pass: the waves with wc == 0 add up the A
-// fragments they hold anyway (VALU, in the load section) for the K-tiles kt = tn (mod tiles_n) of their tile row, so the
-// tiles of a row share the work; partial row tn of cs is summed by vl_colreduce_multi.
+// fragments they hold anyway (v_dot2c_f32_bf16 against ones, after the MFMA section) for the K-tiles kt = tn (mod
+// tiles_n) of their tile row, so the tiles of a row share the work; partial row tn of cs is summed by vl_colreduce_multi.
 // The reads are inline assembly on purpose: the compiler puts s_waitcnt vmcnt(0) in front of the
 // __builtin_amdgcn_ds_read_tr16_b64 intrinsic whenever LDS-DMA loads are outstanding (it cannot prove the read does not
 // alias them), which drains the whole prefetch pipeline before every fragment section -- measured 515 us instead of
@@ -199,17 +199,17 @@ __device__ __forceinline__ bf16x8 tr_frag(unsigned lds_addr) {
   return __builtin_bit_cast(bf16x8, v);
 }
 template <bool T, int OFF>
-__device__ __forceinline__ bf16x8 dw_frag(const unsigned char* st, unsigned st_lds, int o) {
-  if constexpr (T) return tr_frag<OFF>(st_lds + (unsigned)o);
-  else return *reinterpret_cast<const bf16x8*>(st + OFF + o);
+__device__ __forceinline__ bf16x8 dw_frag(unsigned lds_addr) {  // lds_addr: this lane's fragment address in the current stage
+  if constexpr (T) return tr_frag<OFF>(lds_addr);
+  else return *(const __attribute__((address_space(3))) bf16x8*)(uintptr_t)(lds_addr + OFF);
 }
-__device__ __forceinline__ float frag_sum(const bf16x8& f) {  // sum of the 8 bf16 values (fp32)
+// s + one * the 8 bf16 values (fp32 accumulation); one = bf16 {1, 1} on the K-tiles this tile sums, {0, 0} on the others
+// s += one . (dword t of the fragment): two bf16 values, fp32 accumulation (assembly: the dot products have to stay at
+// their place inside the MFMA section)
+__device__ __forceinline__ void frag_dot(float& s, const bf16x8& f, int t, unsigned one_bits) {
   typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
   const u32x4 w = __builtin_bit_cast(u32x4, f);
-  float s = 0.f;
-#pragma unroll
-  for (int t = 0; t < 4; ++t) s += __uint_as_float(w[t] << 16) + __uint_as_float(w[t] & 0xFFFF0000u);
-  return s;
+  asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s) : "s"(one_bits), "v"(w[t]));
 }
 
 // MODE bit 0: the A operand (dY) is row-major (transposing reads), else its K-major image; bit 1: the same for B (X).
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   const int row0 = tm * 256, col0 = tn * 256;
   const int nk = ga.nk;
 
-  const bf16_raw* src[4][2];
+  unsigned soff[4][2];  // per-lane byte offsets from the (uniform) operand base: 32-bit, so the DMA uses the saddr + voffset form
 #pragma unroll
   for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -253,23 +253,24 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
         int gcol = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + lb * 16 + (c & 1) * 8;
         const int lim = (isB ? P.N : P.M) - 8;
         gcol = gcol < lim ? gcol : lim;  // columns past the edge re-read valid data; their products are never stored
-        src[x][j] = (isB ? P.b : P.a) + (long)r * (isB ? P.ldb : P.lda) + gcol;
+        soff[x][j] = (unsigned)(((long)r * (isB ? P.ldb : P.lda) + gcol) * 2);
       } else {
         const int r = 8 * (wave + 8 * j) + (lane >> 3);
         const int lc = (lane & 7) ^ swz3(r);
         int g = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + r;
         const int lim = (isB ? P.N : P.M) - 1;
         g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
-        src[x][j] = (isB ? P.b : P.a) + (long)g * 64 + lc * 8;
+        soff[x][j] = (unsigned)((g * 64 + lc * 8) * 2);
       }
     }
-  const long kstep[2] = {P.ka, P.kb};
+  const long kstep[2] = {P.ka * 2, P.kb * 2};  // bytes
+  const char* const obase[2] = {(const char*)P.a, (const char*)P.b};
   constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
 #define DW_ISSUE(x, kt)                                                                                          \
   do {                                                                                                           \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][0] + (long)(kt) * kstep[(x) >> 1]),                      \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(obase[(x) >> 1] + (long)(kt) * kstep[(x) >> 1] + soff[x][0]),   \
                                      (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + wave * 1024), 16, 0, 0);  \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][1] + (long)(kt) * kstep[(x) >> 1]),                      \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(obase[(x) >> 1] + (long)(kt) * kstep[(x) >> 1] + soff[x][1]),   \
                                      (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + (wave + 8) * 1024), 16, 0, 0); \
   } while (0)
 #define DW_WAIT(issued)                                                                                          \
@@ -290,7 +291,8 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 
   const int frow = lane & 15, fk = lane >> 4;
   const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  int a_o[MI][2], b_o[NJ][2];
+  // LDS byte addresses of this lane's fragments in stage 0; they flip to the other stage in place after every K-tile
+  unsigned a_o[MI][2], b_o[NJ][2];
   {
     // transposed-read lane geometry: group fk owns rows 8 fk .. 8 fk + 7 of a 32-deep step; inside the group lane
     // 4 q + pp addresses row q, columns 4 pp .. 4 pp + 3 of the 4 x 16 block (the second read is 4 rows below)
@@ -300,16 +302,16 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
       const int row = wr * (MI * 16) + i * 16 + frow;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        a_o[i][kk] = TA ? (kk * 32 + 8 * fk + q) * 256 + (((wr * MI + i) ^ hq) << 5) + pp * 8
-                        : row * 128 + (((4 * kk + fk) ^ swz3(row)) << 4);
+        a_o[i][kk] = smem_lds + (TA ? (kk * 32 + 8 * fk + q) * 256 + (((wr * MI + i) ^ hq) << 5) + pp * 8
+                        : row * 128 + (((4 * kk + fk) ^ swz3(row)) << 4));
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int row = wc * (NJ * 16) + j * 16 + frow;
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk)
-        b_o[j][kk] = TB ? (kk * 32 + 8 * fk + q) * 256 + (((wc * NJ + j) ^ hq) << 5) + pp * 8
-                        : row * 128 + (((4 * kk + fk) ^ swz3(row)) << 4);
+        b_o[j][kk] = smem_lds + (TB ? (kk * 32 + 8 * fk + q) * 256 + (((wc * NJ + j) ^ hq) << 5) + pp * 8
+                        : row * 128 + (((4 * kk + fk) ^ swz3(row)) << 4));
     }
   }
   float bsum[2][MI];  // column sums of dY for this wave's output rows (bias gradient partials)
@@ -322,31 +324,35 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
 #define DW_READ_A(st, qm)                                                                                        \
   _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
-    fa[i][0] = dw_frag<TA, (qm) * OFF_A1>(st, st_lds, a_o[i][0]);                                                \
-    fa[i][1] = dw_frag<TA, (qm) * OFF_A1>(st, st_lds, a_o[i][1]);                                                \
+    fa[i][0] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][0]);                                                \
+    fa[i][1] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][1]);                                                \
   }
 #define DW_READ_B(st, qn, fb)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
-    fb[j][0] = dw_frag<TB, OFF_B0 + (qn) * (BH * 128)>(st, st_lds, b_o[j][0]);                                   \
-    fb[j][1] = dw_frag<TB, OFF_B0 + (qn) * (BH * 128)>(st, st_lds, b_o[j][1]);                                   \
+    fb[j][0] = dw_frag<TB, OFF_B0 + (qn) * (BH * 128)>(b_o[j][0]);                                   \
+    fb[j][1] = dw_frag<TB, OFF_B0 + (qn) * (BH * 128)>(b_o[j][1]);                                   \
   }
-  // (after the MFMA section of a quadrant that consumed fresh A fragments: their column sums, on the selected K-tiles)
+  // after the second MFMA section of a quadrant row, on the selected K-tiles: the column sums of its A fragments
+  // (v_dot2c_f32_bf16 against {1, 1}: 4 per fragment; consecutive ones are independent)
 #define DW_BIAS(qm)                                                                                              \
   do {                                                                                                           \
     if (bias_now) {                                                                                              \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i) bsum[qm][i] += frag_sum(fa[i][0]) + frag_sum(fa[i][1]);     \
+      _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                              \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) frag_dot(bsum[qm][i], fa[i][kk], t, 0x3F803F80u);           \
     }                                                                                                            \
   } while (0)
-#define DW_MFMA(qm, qn, fb)                                                                                      \
+#define DW_MFMA(qm, qn, fb)                                                                                \
   do {                                                                                                           \
     __builtin_amdgcn_s_barrier();                                                                                \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     __builtin_amdgcn_s_setprio(1);                                                                               \
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
-    _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                               \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                               \
+    _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                             \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
         acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[qm][qn][i][j], 0, 0, 0); \
+    }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
     __builtin_amdgcn_s_barrier();                                                                                \
@@ -364,9 +370,8 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   if (late) __builtin_amdgcn_s_barrier();  // stagger
 
   for (int kt = 0; kt < nk; ++kt) {
-    const unsigned char* st = smem + (kt & 1) * STAGE;
-    const unsigned st_lds = smem_lds + (kt & 1) * STAGE;
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+    const unsigned flip = (kt & 1) ? 0u - (unsigned)STAGE : (unsigned)STAGE;  // to the other stage
     const bool bias_now = bias_wave && (kt % P.tiles_n) == tn;
     DW_READ_B(st, 0, fb0);
     __builtin_amdgcn_sched_barrier(0);
@@ -375,11 +380,15 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     DW_WAIT(n1);
     DW_MFMA(0, 0, fb0);
     DW_READ_B(st, 1, fb1);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { b_o[j][0] += flip; b_o[j][1] += flip; }
     if (n1) DW_ISSUE(1, kt + 1);
     DW_WAIT(n1);
     DW_MFMA(0, 1, fb1);
     DW_BIAS(0);
     DW_READ_A(st, 1);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) { a_o[i][0] += flip; a_o[i][1] += flip; }
     if (n2) DW_ISSUE(0, kt + 2);
     DW_WAIT(n2);
     DW_MFMA(1, 1, fb1);
