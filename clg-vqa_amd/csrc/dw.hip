@@ -321,11 +321,13 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     for (int i = 0; i < MI; ++i) bsum[qm][i] = 0.f;
   const bool bias_wave = P.cs != nullptr && wc == 0;
 
-  bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
-#define DW_READ_A(st, qm)                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                              \
-    fa[i][0] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][0]);                                                \
-    fa[i][1] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][1]);                                                \
+  // fa[0]: A fragments of quadrant row 0 -- rows i >= MI / 2 are read one phase EARLY (in the otherwise read-free last
+  // phase of the previous K-tile), which levels the LDS reads of the four phases from 12 / 4 / 8 / 0 to 8 / 4 / 8 / 4 fragments
+  bf16x8 fa[2][MI][2], fb0[NJ][2], fb1[NJ][2];
+#define DW_READ_A(st, qm, i0, i1)                                                                                \
+  _Pragma("unroll") for (int i = (i0); i < (i1); ++i) {                                                         \
+    fa[qm][i][0] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][0]);                                                        \
+    fa[qm][i][1] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][1]);                                                        \
   }
 #define DW_READ_B(st, qn, fb)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     if (bias_now) {                                                                                              \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
       _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                              \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i) frag_dot(bsum[qm][i], fa[i][kk], t, 0x3F803F80u);           \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) frag_dot(bsum[qm][i], fa[qm][i][kk], t, 0x3F803F80u);           \
     }                                                                                                            \
   } while (0)
 #define DW_MFMA(qm, qn, fb)                                                                                \
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                             \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
-        acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[i][kk], acc[qm][qn][i][j], 0, 0, 0); \
+        acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[qm][i][kk], acc[qm][qn][i][j], 0, 0, 0); \
     }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
+  DW_READ_A(st, 0, MI / 2, MI);            // K-tile 0's early half
   if (late) __builtin_amdgcn_s_barrier();  // stagger
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     const bool bias_now = bias_wave && (kt % P.tiles_n) == tn;
     DW_READ_B(st, 0, fb0);
     __builtin_amdgcn_sched_barrier(0);
-    DW_READ_A(st, 0);
+    DW_READ_A(st, 0, 0, MI / 2);
     if (n1) DW_ISSUE(3, kt + 1);
     DW_WAIT(n1);
     DW_MFMA(0, 0, fb0);
@@ -386,12 +389,15 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     DW_WAIT(n1);
     DW_MFMA(0, 1, fb1);
     DW_BIAS(0);
-    DW_READ_A(st, 1);
+    DW_READ_A(st, 1, 0, MI);
 #pragma unroll
     for (int i = 0; i < MI; ++i) { a_o[i][0] += flip; a_o[i][1] += flip; }
     if (n2) DW_ISSUE(0, kt + 2);
     DW_WAIT(n2);
     DW_MFMA(1, 1, fb1);
+    // (A0 of K-tile kt + 1 landed with the wait of the previous phase and is visible after its barriers; the fragment
+    // addresses already point to that stage)
+    DW_READ_A(st, 0, MI / 2, MI);
     if (n2) DW_ISSUE(2, kt + 2);
     DW_WAIT(n2);
     DW_MFMA(1, 0, fb0);
