@@ -70,7 +70,7 @@ _SIGS = {
     "vl_embed_scatter_add": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P]),
     "vl_loc_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
     "vl_loc_linear_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
-    "vl_adamw": (c_int, [P, P, P, P, c_int64, P, P, P, c_int64, c_float, c_float, c_float, c_int64, c_int, c_float,
+    "vl_adamw": (c_int, [P, P, P, P, c_int64, P, P, P, c_int64, c_float, c_float, c_float, c_int64, P, c_int, c_float,
                          P, c_float, P, c_float, c_float, P, c_int, P, c_int64, c_int64, c_int64, P]),
     "vl_sumsq": (c_int, [P, c_int64, P, P]),
     "vl_sumsq_flagged": (c_int, [P, c_int64, P, P, c_int64, c_int64, c_int64, P]),

@@ -166,7 +166,11 @@ struct DwProb {
   // cs (may be NULL): fp32 [tiles_n, M] partial column sums of dY (the bias gradient; see below)
   long lda, ldb; float* cs;
 };
-struct DwArgs { DwProb p[MAXT]; int nprob; int nk; int total_tiles; int accumulate; };
+// sk_slots / sk_flags (stream-K form only): caller-owned workspace -- one partial-tile slot (SK_SLOT_FLOATS floats) and one
+// hand-off flag (zero between launches) per workgroup
+struct DwArgs { DwProb p[MAXT]; int nprob; int nk; int total_tiles; int accumulate; float* sk_slots; unsigned* sk_flags; };
+constexpr int SK_SLOT_F4 = 34 * 512;              // float4 per slot: 32 accumulator registers + 2 bias-sum registers per thread
+constexpr long SK_SLOT_FLOATS = 4L * SK_SLOT_F4;  // 278 528 bytes
 
 __device__ __forceinline__ int swz3(int row) {
   return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 4) ^ (row >> 2)) & 1) << 2);
@@ -212,8 +216,21 @@ __device__ __forceinline__ void frag_dot(float& s, const bf16x8& f, int t, unsig
   asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(s) : "s"(one_bits), "v"(w[t]));
 }
 
-// MODE bit 0: the A operand (dY) is row-major (transposing reads), else its K-major image; bit 1: the same for B (X).
-template <int MODE>
+// MODE bit 0: the A operand (dY) is row-major (transposing reads), else its K-major image; bit 1: the same for X (X).
+//
+// SK = true, the STREAM-K form (a fixed CU budget for the weight gradients): the grid is G workgroups, G chosen by the
+// caller (not by the tile count), and the linearised iteration space {tile} x {K-tile} of the launch is cut into G equal
+// contiguous ranges.  A workgroup walks its range as segments (tile, [k0, k0 + len)): a segment that starts a tile
+// (k0 == 0) OWNS it -- it runs the epilogue, after adding the partial accumulators of the workgroups that cover the rest of
+// the tile's K range, in K order (fixed summation order: deterministic for a given G); a segment with k0 > 0 -- only ever
+// the FIRST segment of a workgroup -- stores its raw accumulators (lane-linear, the owner runs the same code) into its
+// slot of the caller's workspace and raises its flag.  Owners only wait for workgroups with a HIGHER index, and only for
+// their first segment, which waits for nothing: no cycle; G <= the CU count keeps every workgroup resident or next in
+// the dispatch order.  Hand-off protocol (per-XCD L2s are not coherent): plain 16-byte stores -> every wave's
+// s_waitcnt vmcnt(0) -> workgroup barrier -> lane 0: agent-scope release fence, s_waitcnt vmcnt(0), relaxed agent-scope
+// flag store | relaxed agent-scope poll -> agent-scope acquire fence, s_waitcnt vmcnt(0) -> workgroup barrier -> plain
+// loads; the owner then clears the flag (flags are zero between launches).
+template <int MODE, bool SK>
 __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   constexpr bool TA = (MODE & 1) != 0, TB = (MODE & 2) != 0;
   constexpr int WC = 4;                        // wave grid 2 (M) x 4 (N)
@@ -226,19 +243,39 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   const int wr = wave / WC, wc = wave % WC;
   const bool late = wave >= 4;
 
-  const int nwg = ga.total_tiles;
+  // XCD-contiguous virtual workgroup index: neighbours in the work list (tiles that share an operand panel; stream-K:
+  // the two sides of a hand-off) sit on one XCD, i.e. behind one L2
+  const int nwg = SK ? (int)gridDim.x : ga.total_tiles;
   const int bid = blockIdx.x;
   const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
   const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int nk_tile = ga.nk;
+  // this workgroup's range of the iteration space
+  long it, it_end;
+  long sk_per = 0; int sk_rem = 0;
+  if (SK) {
+    const long total = (long)ga.total_tiles * nk_tile;
+    sk_per = total / nwg; sk_rem = (int)(total - sk_per * nwg);
+    it = swz * sk_per + (swz < sk_rem ? swz : sk_rem);
+    it_end = it + sk_per + (swz < sk_rem ? 1 : 0);
+  } else {
+    it = (long)swz * nk_tile; it_end = it + nk_tile;
+  }
+  const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int frow = lane & 15, fk = lane >> 4;
+
+ while (it < it_end) {  // segments (SK = false: exactly one, the whole tile)
+  const int tile_id = SK ? (int)(it / nk_tile) : swz;
+  const int k0 = SK ? (int)(it - (long)tile_id * nk_tile) : 0;
+  const int nk = SK ? (int)((it_end - it) < (long)(nk_tile - k0) ? (it_end - it) : (long)(nk_tile - k0)) : nk_tile;
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < MAXT; ++i)
-    if (i < ga.nprob && swz >= ga.p[i].tile0) pi = i;
+    if (i < ga.nprob && tile_id >= ga.p[i].tile0) pi = i;
   const DwProb& P = ga.p[pi];
-  const int lt = swz - P.tile0;
+  const int lt = tile_id - P.tile0;
   const int tm = lt / P.tiles_n, tn = lt - tm * P.tiles_n;
   const int row0 = tm * 256, col0 = tn * 256;
-  const int nk = ga.nk;
 
   unsigned soff[4][2];  // per-lane byte offsets from the (uniform) operand base: 32-bit, so the DMA uses the saddr + voffset form
 #pragma unroll
@@ -264,7 +301,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
       }
     }
   const long kstep[2] = {P.ka * 2, P.kb * 2};  // bytes
-  const char* const obase[2] = {(const char*)P.a, (const char*)P.b};
+  const char* const obase[2] = {(const char*)P.a + (long)k0 * kstep[0], (const char*)P.b + (long)k0 * kstep[1]};
   constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
 #define DW_ISSUE(x, kt)                                                                                          \
   do {                                                                                                           \
@@ -289,8 +326,6 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int frow = lane & 15, fk = lane >> 4;
-  const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   // LDS byte addresses of this lane's fragments in stage 0; they flip to the other stage in place after every K-tile
   unsigned a_o[MI][2], b_o[NJ][2];
   {
@@ -375,7 +410,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
     const unsigned flip = (kt & 1) ? 0u - (unsigned)STAGE : (unsigned)STAGE;  // to the other stage
-    const bool bias_now = bias_wave && (kt % P.tiles_n) == tn;
+    const bool bias_now = bias_wave && ((k0 + kt) % P.tiles_n) == tn;
     DW_READ_B(st, 0, fb0);
     __builtin_amdgcn_sched_barrier(0);
     DW_READ_A(st, 0, 0, MI / 2);
@@ -410,6 +445,78 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 #undef DW_READ_B
 #undef DW_MFMA
 #undef DW_BIAS
+
+  if (SK) {
+    if (k0 != 0) {
+      // contributor: raw accumulators (+ bias partial sums) -> this workgroup's slot, then the flag.  Register r of
+      // thread tid at float4 index r * 512 + tid: every store instruction of a wave is one contiguous KB
+      float4* slot = reinterpret_cast<float4*>(ga.sk_slots + (long)swz * SK_SLOT_FLOATS) + tid;
+#pragma unroll
+      for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              const f32x4 v = acc[qm][qn][i][j];
+              slot[(((qm * 2 + qn) * MI + i) * NJ + j) * 512] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+      slot[32 * 512] = make_float4(bsum[0][0], bsum[0][1], bsum[0][2], bsum[0][3]);
+      slot[33 * 512] = make_float4(bsum[1][0], bsum[1][1], bsum[1][2], bsum[1][3]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the fence's own wait)
+        __hip_atomic_store(ga.sk_flags + swz, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      it += nk;
+      continue;
+    }
+    // owner: add the partial tiles of the workgroups that cover [nk, nk_tile) of this tile, in K order
+    int covered = nk;
+    for (int c = swz + 1; covered < nk_tile; ++c) {
+      if (tid == 0) {
+        while (__hip_atomic_load(ga.sk_flags + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __syncthreads();
+      const float4* slot = reinterpret_cast<const float4*>(ga.sk_slots + (long)c * SK_SLOT_FLOATS) + tid;
+      // (two halves of 16 loads each, fenced: all 32 in flight at once would need 128 more registers than there are)
+#pragma unroll
+      for (int qm = 0; qm < 2; ++qm) {
+        float4 v[2][MI][NJ];
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) v[qn][i][j] = slot[(((qm * 2 + qn) * MI + i) * NJ + j) * 512];
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+              acc[qm][qn][i][j][0] += v[qn][i][j].x; acc[qm][qn][i][j][1] += v[qn][i][j].y;
+              acc[qm][qn][i][j][2] += v[qn][i][j].z; acc[qm][qn][i][j][3] += v[qn][i][j].w;
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      {
+        const float4 b0 = slot[32 * 512], b1 = slot[33 * 512];
+        bsum[0][0] += b0.x; bsum[0][1] += b0.y; bsum[0][2] += b0.z; bsum[0][3] += b0.w;
+        bsum[1][0] += b1.x; bsum[1][1] += b1.y; bsum[1][2] += b1.z; bsum[1][3] += b1.w;
+      }
+      __syncthreads();  // (every thread's loads of the slot have returned: the adds above consumed them)
+      if (tid == 0) __hip_atomic_store(ga.sk_flags + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long c_len = sk_per + (c < sk_rem ? 1 : 0);  // workgroup c's range starts at this tile's K-tile `covered`
+      covered += (int)(c_len < (long)(nk_tile - covered) ? c_len : (long)(nk_tile - covered));
+    }
+  }
 
   if (bias_wave) {  // rows 8 fk .. 8 fk + 7 of every 32-deep step were summed per lane group: add the 4 groups
 #pragma unroll
@@ -459,6 +566,12 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
           }
         }
     }
+  it += nk;
+  if (SK && it < it_end) {  // the epilogue's stores share vmcnt with the next segment's counted DMA waits: drain them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+ }  // segments
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -466,6 +579,12 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) 
 }  // namespace
 
 extern "C" int64_t vl_blocked_elems(int64_t M, int64_t N) { return ((M + 63) / 64) * 64 * N; }
+
+// stream-K workspace: [flags: 256 x 4 B, padded to 4 KB][budget partial-tile slots]
+static constexpr int64_t SK_FLAG_BYTES = 4096;
+extern "C" int64_t vl_dw_streamk_ws_bytes(int64_t budget) {
+  return budget > 0 ? SK_FLAG_BYTES + budget * SK_SLOT_FLOATS * 4 : 0;
+}
 
 // tab: HOST array of n x VL_TR_FIELDS int64 {src, ld, N, dst, colsum_partial (0 = none), 0}
 extern "C" int vl_transpose_blocked(const int64_t* tab, int64_t n, int64_t M, int64_t max_blocks, void* stream) {
@@ -532,9 +651,27 @@ extern "C" int vl_colreduce_multi(const int64_t* tab, int64_t n, int accumulate,
 
 // probs: HOST array of nprob x VL_DW_FIELDS int64 {aT, a_rows_total, bT, b_rows_total, out, ldo, mask (0 = none), M, N, 0}
 // (rowmajor: {dY, lda, X, ldb, out, ldo, mask, M, N, colsum partials [ceil(N / 256), M] or 0})
-static int dw_launch(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, int mode, void* stream) {
+template <int MODE, bool SK>
+static int dw_launch_t(const DwArgs& a, int grid, const char* fn, void* stream) {
+  const size_t lds = 2 * 65536;
+  static bool attr_set = false;  // per instantiation; idempotent, so a race only repeats the call
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dw_grouped_kernel<MODE, SK>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return vl_set_error(-3, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((dw_grouped_kernel<MODE, SK>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+  VL_CHECK_LAUNCH(fn);
+  return 0;
+}
+
+// budget > 0: the stream-K form on `budget` workgroups with the caller's workspace `ws` (vl_dw_streamk_ws_bytes(budget)
+// bytes, zero-filled once by the caller; launches that share it must be ordered on one stream)
+static int dw_launch(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, int mode, int64_t budget, void* ws,
+                     int64_t ws_bytes, void* stream) {
   const bool rowmajor = mode != 0;
-  const char* fn = rowmajor ? "vl_dw_grouped_rowmajor" : "vl_dw_grouped";
+  const char* fn = budget > 0 ? "vl_dw_grouped_streamk" : rowmajor ? "vl_dw_grouped_rowmajor" : "vl_dw_grouped";
   VL_CHECK_ARG(mode >= 0 && mode <= 3, "%s: mode must be 0..3", fn);
   VL_CHECK_ARG(probs && nprob >= 1 && nprob <= MAXT && K >= 1, "%s: bad arguments", fn);
   VL_CHECK_ARG(!rowmajor || K % 64 == 0, "%s: the row count must be a multiple of 64 (got %lld)", fn, (long long)K);
@@ -563,34 +700,47 @@ static int dw_launch(const int64_t* probs, int64_t nprob, int64_t K, int accumul
     tiles += ((p.M + 255) / 256) * p.tiles_n;
   }
   a.total_tiles = tiles;
-  const size_t lds = 2 * 65536;
-  static bool attr_set[4] = {false, false, false, false};
-  const void* kfn = mode == 0   ? reinterpret_cast<const void*>(&dw_grouped_kernel<0>)
-                    : mode == 1 ? reinterpret_cast<const void*>(&dw_grouped_kernel<1>)
-                    : mode == 2 ? reinterpret_cast<const void*>(&dw_grouped_kernel<2>)
-                                : reinterpret_cast<const void*>(&dw_grouped_kernel<3>);
-  if (!attr_set[mode]) {
-    hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return vl_set_error(-3, "%s: hipFuncSetAttribute: %s", fn, hipGetErrorString(e));
-    attr_set[mode] = true;
+  if (budget > 0) {
+    VL_CHECK_ARG(budget <= 256, "%s: the workgroup budget must be <= 256 (one 8-wave workgroup per CU; owners wait for resident workgroups)", fn);
+    VL_CHECK_ARG(ws && al16(ws) && ws_bytes >= vl_dw_streamk_ws_bytes(budget), "%s: workspace missing / too small / unaligned", fn);
+    // a range of less than two K-tiles is not worth a hand-off: shrink the grid (the partition stays valid for any grid)
+    int64_t g = budget;
+    const int64_t total = (int64_t)tiles * a.nk;
+    if (g > total / 2) g = total / 2 > 0 ? total / 2 : 1;
+    a.sk_flags = reinterpret_cast<unsigned*>(ws);
+    a.sk_slots = reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + SK_FLAG_BYTES);
+    switch (mode) {
+      case 0: return dw_launch_t<0, true>(a, (int)g, fn, stream);
+      case 1: return dw_launch_t<1, true>(a, (int)g, fn, stream);
+      case 2: return dw_launch_t<2, true>(a, (int)g, fn, stream);
+      default: return dw_launch_t<3, true>(a, (int)g, fn, stream);
+    }
   }
   switch (mode) {
-    case 0: hipLaunchKernelGGL(dw_grouped_kernel<0>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a); break;
-    case 1: hipLaunchKernelGGL(dw_grouped_kernel<1>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a); break;
-    case 2: hipLaunchKernelGGL(dw_grouped_kernel<2>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a); break;
-    default: hipLaunchKernelGGL(dw_grouped_kernel<3>, dim3(tiles), dim3(512), lds, (hipStream_t)stream, a); break;
+    case 0: return dw_launch_t<0, false>(a, tiles, fn, stream);
+    case 1: return dw_launch_t<1, false>(a, tiles, fn, stream);
+    case 2: return dw_launch_t<2, false>(a, tiles, fn, stream);
+    default: return dw_launch_t<3, false>(a, tiles, fn, stream);
   }
-  VL_CHECK_LAUNCH(fn);
-  return 0;
 }
 
 extern "C" int vl_dw_grouped(const int64_t* probs, int64_t nprob, int64_t K, int accumulate, void* stream) {
-  return dw_launch(probs, nprob, K, accumulate, 0, stream);
+  return dw_launch(probs, nprob, K, accumulate, 0, 0, nullptr, 0, stream);
 }
 extern "C" int vl_dw_grouped_rowmajor(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, void* stream) {
-  return dw_launch(probs, nprob, rows, accumulate, 3, stream);
+  return dw_launch(probs, nprob, rows, accumulate, 3, 0, nullptr, 0, stream);
 }
 // mode bit 0: dY row-major (else its K-major image: fields 0 / 1 = image, image columns), bit 1: the same for X
 extern "C" int vl_dw_grouped_mixed(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, int mode, void* stream) {
-  return dw_launch(probs, nprob, rows, accumulate, mode, stream);
+  return dw_launch(probs, nprob, rows, accumulate, mode, 0, nullptr, 0, stream);
+}
+// The stream-K form (see dw_grouped_kernel): the same products on a FIXED number of workgroups -- `budget` CUs of the chip
+// for the weight gradients, the rest stays with whatever runs beside them -- each walking an equal share of the launch's
+// (tile, K-tile) iterations; tiles cut by a share boundary are completed by their owner from the partial tiles in `ws`.
+// Results are deterministic for a given budget (fixed summation order), and differ from the one-workgroup-per-tile form
+// by fp32 re-association only.
+extern "C" int vl_dw_grouped_streamk(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, int mode,
+                                     int64_t budget, void* ws, int64_t ws_bytes, void* stream) {
+  VL_CHECK_ARG(budget >= 1, "vl_dw_grouped_streamk: budget must be >= 1");
+  return dw_launch(probs, nprob, rows, accumulate, mode, budget, ws, ws_bytes, stream);
 }

@@ -407,14 +407,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
                                                     float gscale_const, const float* sumsq_ptr, float max_norm, float post,
                                                     float* sumsq_next, int zero_grad,
                                                     const unsigned char* __restrict__ row_flags, long fl_beg4, long fl_end4,
-                                                    int fl_row4) {
+                                                    int fl_row4, const int64_t* __restrict__ seg_step, int correct_bias) {
   // segment table (every segment starts on a multiple of 4 elements) -> LDS, in float4 units
   __shared__ int s_end4[ADAMW_MAX_SEG];
-  __shared__ float s_lr[ADAMW_MAX_SEG], s_wd[ADAMW_MAX_SEG];
+  __shared__ float s_lr[ADAMW_MAX_SEG], s_wd[ADAMW_MAX_SEG], s_bc[ADAMW_MAX_SEG];
   for (int i = threadIdx.x; i < nseg; i += 256) {
     s_end4[i] = (int)(seg_end[i] >> 2);
     s_lr[i] = seg_lr[i] < 0.f ? -1.f : seg_lr[i] * lr_mult;
     s_wd[i] = seg_wd[i];
+    // per-segment step counts (pytorch_transformers.AdamW keeps state['step'] per parameter and advances it only when
+    // that parameter has a gradient): the same double-precision expression the host evaluates for the uniform case
+    float b = bc;
+    if (seg_step) {
+      const double t = (double)(seg_step[i] > 0 ? seg_step[i] : 1);
+      b = correct_bias ? (float)(sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t))) : 1.0f;
+    }
+    s_bc[i] = b;
   }
   __syncthreads();
   float gs = gscale_ptr ? *gscale_ptr : gscale_const;
@@ -435,8 +443,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     }
     return lo;
   };
-  auto update4 = [&](long i, float lr, float wd) {
-    const float step = lr * bc, decay = 1.f - lr * wd;
+  auto update4 = [&](long i, float lr, float wd, float bcs) {
+    const float step = lr * bcs, decay = 1.f - lr * wd;
     float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<float4*>(g)[i];
     float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
 #define VL_ADAM1(c)                                          \
@@ -464,7 +472,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     // weight decay, no traffic), like `if p.grad is None: continue` in pytorch_transformers.AdamW -- M3P's 93 M never-used
     // parameters are 2.6 GB per step otherwise
     if (s_lr[sg] < 0.f) continue;
-    update4(i, s_lr[sg], s_wd[sg]);
+    update4(i, s_lr[sg], s_wd[sg], s_bc[sg]);
   }
   // flagged table, one wave per row: rows that never received a gradient have g = m = v = 0, so their AdamW update is
   // exactly p *= decay (8 B/param instead of 32 B/param, bit-identical to the dense path) -- and with the reference's
@@ -481,7 +489,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
     for (long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6; row < nrows; row += nwaves) {
       const long base = fl_beg4 + row * fl_row4;
       if (row_flags[row]) {
-        for (int c = lane; c < fl_row4; c += 64) update4(base + c, lr, wd);
+        for (int c = lane; c < fl_row4; c += 64) update4(base + c, lr, wd, s_bc[sg]);
       } else if (!noop) {
         for (int c = lane; c < fl_row4; c += 64) {
           float4 pp = reinterpret_cast<float4*>(p)[base + c];
@@ -674,7 +682,7 @@ extern "C" int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw,
 
 extern "C" int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1,
-                        float beta2, float eps, int64_t step, int correct_bias, float lr_mult,
+                        float beta2, float eps, int64_t step, const int64_t* seg_step, int correct_bias, float lr_mult,
                         const float* grad_scale_dev, float grad_scale, const float* sumsq_dev, float max_norm, float post,
                         float* sumsq_next, int zero_grad, const uint8_t* row_flags,
                         int64_t flag_begin, int64_t flag_rows, int64_t flag_row_len, void* stream) {
@@ -692,7 +700,7 @@ extern "C" int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_av
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, param, grad,
                      exp_avg, exp_avg_sq, (long)(n / 4), seg_end, seg_lr, seg_wd, (int)nseg, beta1, beta2, eps, bc, lr_mult,
                      grad_scale_dev, grad_scale, sumsq_dev, max_norm, post, sumsq_next, zero_grad, row_flags, (long)(flag_begin / 4),
-                     (long)((flag_begin + flag_rows * flag_row_len) / 4), (int)(flag_row_len / 4));
+                     (long)((flag_begin + flag_rows * flag_row_len) / 4), (int)(flag_row_len / 4), seg_step, correct_bias);
   VL_CHECK_LAUNCH("vl_adamw");
   return 0;
 }

@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void gqa_loss_kernel(LossArgs a) {
   }
   block_argmax(zmax, zarg, sv, si);
   block_argmax(tmax, targ, sv, si);
+  // a row with a NaN logit (every `>` is false) or with -inf everywhere leaves the sentinel: fall back to index 0 -- the
+  // loss of such a row is NaN through `se`, as in the reference, and no index ever leaves the row
+  if ((unsigned)zarg >= (unsigned)C) zarg = 0;
+  if ((unsigned)targ >= (unsigned)C) targ = 0;
   const int label = targ;
   float se = 0.f;
 #pragma unroll
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256) void gqa_loss_kernel(LossArgs a) {
     for (int k = 0; k < MAXPT; ++k)
       if (q[k] > v) { v = q[k]; i = tid + 256 * k; }
     block_argmax(v, i, sv, si);
+    if ((unsigned)i >= (unsigned)C) i = 0;  // NaN probabilities: nothing compares greater (see above)
     if (tid == 0) s_top[r] = i;
 #pragma unroll
     for (int k = 0; k < MAXPT; ++k)

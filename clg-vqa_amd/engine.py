@@ -14,6 +14,8 @@ Data layout in HBM (B = batch, T text tokens, V boxes, S = T + V, M = B*S rows, 
   qkv32   [M,3H] fp32, columns [Q|K|V]             ctx (hi,lo) [M,H] bf16
   u16/h   [M,I] bf16 pre-activation / GELU output  weights: (hi,lo) [N,K] + transposed hi [K,N], rebuilt per step
 """
+import weakref
+
 import numpy as np
 import torch
 
@@ -200,6 +202,30 @@ def _f32_bits(x):
     return int(np.float32(x).view(np.uint32))
 
 
+class ArenaTicket(object):
+    """Held by the autograd node of a training forward (``ctx.ticket``).  An arena is busy while its ticket is alive and
+    its backward has not run: a forward whose graph is dropped (an exception in the loss, a skipped step, a logging call
+    outside no_grad) releases its arena when the node dies instead of pinning it forever."""
+    __slots__ = ("__weakref__",)
+
+
+def arena_busy(a):
+    if not a.in_flight:
+        return False
+    t = a.ticket
+    if t is not None and t() is None:  # the autograd node that owned the saved activations is gone
+        a.in_flight, a.ticket = False, None
+        return False
+    return True
+
+
+def arena_claim(ctx, a):
+    """Tie a training forward's arena to the life of its autograd node."""
+    if a.in_flight:
+        ctx.ticket = ArenaTicket()
+        a.ticket = weakref.ref(ctx.ticket)
+
+
 class StackArena(object):
     """Device buffers of the layer stack for one (B, S) shape, allocated ONCE and re-used every step (no allocator
     traffic on the hot path; sized for 288 GB of HBM: ~0.55 GB per layer at c2):
@@ -229,6 +255,7 @@ class StackArena(object):
         self.addmask, self.row_post = f32(M), f32(M)
         self.rows0 = torch.arange(B, dtype=torch.int64, device=device) * S  # the pooled row of every sample
         self.in_flight = False  # a training forward whose backward has not run yet owns the saved activations
+        self.ticket = None      # weakref to the ArenaTicket of that forward's autograd node (arena_busy)
         # workspace of the small-M GEMM path: the B-row products of the pooled last layer (and every product of a batch
         # with few rows); launches of one stream share it
         lib = _lib.lib()
@@ -253,8 +280,10 @@ class StackArena(object):
                 # du's image + its column-sum partials per layer (VL_ST_FUSE_IMAGES): written by the GELU' epilogue on
                 # the main stream while the side stream may still be reading the layer above's
                 self.t_du_l, self.cs_du_l = b16(L, ni), f32(L, 8 * ((M + 255) // 256), I)
-            mb = (M + 63) // 64
-            self.cs_qkv, self.cs_u = f32(mb, 3 * H), f32(mb, I)
+            # column-sum partials: one row per 64-row block (re-layout pass) or ceil(H / 256) rows per problem
+            # (row-major dW GEMM: q | k | v at csq + {0, 1, 2} * tq * H, stack.hip) -- whichever is larger
+            mb, tq = (M + 63) // 64, (H + 255) // 256
+            self.cs_qkv, self.cs_u = f32(max(mb, 3 * tq), 3 * H), f32(max(mb, tq), I)
             self.fork = torch.cuda.Event()
             self.fork.record()  # materialises the hipEvent_t behind the handle
 
@@ -327,7 +356,7 @@ class LayerStack(object):
         key = (B, S, str(device), need_grad, rowmajor)
         lst = self._arenas.setdefault(key, [])
         for a in lst:
-            if not a.in_flight:
+            if not arena_busy(a):
                 return a
         a = StackArena(len(self.specs), B, S, self.H, self.I, self.nh, device, need_grad, images=not rowmajor)
         lst.append(a)
@@ -787,10 +816,14 @@ class TrunkFunction(torch.autograd.Function):
             ops.set_stream(None)
         ctx.engine = engine
         ctx.sv = sv
+        arena_claim(ctx, sv["arena"])
         return out
 
     @staticmethod
     def backward(ctx, dx):
+        if ctx.sv is None:
+            raise RuntimeError("clg_vqa_amd: the trunk's saved activations were released by its first backward "
+                               "(retain_graph / double backward are not supported by the native trunk)")
         ops.set_stream(torch.cuda.current_stream().cuda_stream)
         try:
             grads = ctx.engine.backward(ctx.sv, dx)

@@ -18,7 +18,7 @@ sizes the fused kernels do not cover (not multiples of 64).
 import torch
 
 from . import _lib, ops
-from .engine import linear_params
+from .engine import arena_busy, arena_claim, linear_params
 from .ops import BF16, EPI_F32, ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH
 
 HEAD_SEED_SITE = 4090  # dropout site of the pooled vector (the stack uses 16 l + 3 .. 16 l + 5, the embeddings 1 and 2)
@@ -37,6 +37,7 @@ class HeadArena(object):
         lib = _lib.lib()
         self.B = B
         self.in_flight = False
+        self.ticket = None
         self.x_hi, self.x_lo = b16(B, H), b16(B, H)          # only when the trunk did not hand the split over
         self.z1, self.y1_hi, self.y1_lo = f32(B, P), b16(B, P), b16(B, P)
         self.z2, self.g32 = f32(B, C), f32(B, C)
@@ -67,7 +68,7 @@ class TaskHead(object):
     def arena(self, B, device):
         lst = self._arenas.setdefault((B, str(device)), [])
         for a in lst:
-            if not a.in_flight:
+            if not arena_busy(a):
                 return a
         a = HeadArena(B, self.H, self.P, self.C, self.NL, device)
         lst.append(a)
@@ -118,6 +119,7 @@ class HeadFunction(torch.autograd.Function):
             ops.set_stream(None)
         if need_grad:
             ar.in_flight = True
+            arena_claim(ctx, ar)
             ctx.head, ctx.ar, ctx.x_hi, ctx.pw = head, ar, x_hi, (pwp, pw1, pw2)
             ctx.p, ctx.seed, ctx.act, ctx.x_shape = p, seed, act, x.shape
         return logits

@@ -386,11 +386,12 @@ def loc_linear_bwd(loc, dy32, dw, db, R, L, H):
 
 def adamw(param, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, seg_wd, beta1, beta2, eps, step, correct_bias, lr_mult,
           grad_scale_dev=None, grad_scale=1.0, zero_grad=False, row_flags=None, flag_begin=0, flag_rows=0,
-          flag_row_len=0, sumsq=None, max_norm=0.0, post=1.0, sumsq_next=None):
-    """sumsq (device scalar) switches the device-side clip: scale = min(1, max_norm / (sqrt(sumsq) * post + 1e-6)) * post."""
+          flag_row_len=0, sumsq=None, max_norm=0.0, post=1.0, sumsq_next=None, seg_step=None):
+    """sumsq (device scalar) switches the device-side clip: scale = min(1, max_norm / (sqrt(sumsq) * post + 1e-6)) * post.
+    seg_step (device int64 [nseg], optional): per-segment step counts for the bias correction (default: `step` everywhere)."""
     _lib.check(_lib.lib().vl_adamw(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), param.numel(), _p(seg_end),
                                    _p(seg_lr), _p(seg_wd), seg_end.numel(), float(beta1), float(beta2), float(eps),
-                                   int(step), int(bool(correct_bias)), float(lr_mult), _p(grad_scale_dev),
+                                   int(step), _p(seg_step), int(bool(correct_bias)), float(lr_mult), _p(grad_scale_dev),
                                    float(grad_scale), _p(sumsq), float(max_norm), float(post), _p(sumsq_next),
                                    int(bool(zero_grad)), _p(row_flags), flag_begin, flag_rows,
                                    flag_row_len, _stream()), "vl_adamw")

@@ -14,9 +14,11 @@ Reference semantics restated:
   (volta/apex/apex/parallel/distributed.py:425-475, :491-510).
 
 MI355X design: all parameters live in one flat fp32 arena (``p.data`` are views), with sibling arenas for the
-gradient and the two Adam moments.  One step = gather grads into the flat arena (multi-tensor copy), bucketed
-RCCL all-reduce directly on slices of that arena (no flatten/unflatten copies), one sum-of-squares kernel, and one
-AdamW kernel that also applies the clip coefficient (read from device memory -- no host sync) and zeroes the grads.
+gradient and the two Adam moments.  The native layer stack writes every layer gradient straight into its arena view
+(``grad_sink``; only the embeddings / pooler / classifier gradients arrive from autograd and are copied by one
+multi-tensor copy); per-layer RCCL all-reduces run on slices of that arena behind each layer's weight-gradient kernels
+(no flatten / unflatten copies), the word-embedding rows are exchanged sparsely, then one sum-of-squares kernel and one
+AdamW kernel that computes the clip coefficient itself (from device memory -- no host sync) and zeroes the grads.
 """
 import torch
 import torch.distributed as dist
@@ -185,6 +187,11 @@ class FusedAdamW(object):
         self.warmup_steps, self.t_total = warmup_steps, t_total
         self.sched_step = 0  # scheduler.step() count (train_task.py:335)
         self.opt_step = 0
+        # pytorch_transformers.AdamW keeps state['step'] PER PARAMETER and advances it only on steps where the parameter has
+        # a gradient: a segment that first receives one at step k > 1, or misses steps, gets its own bias correction.  The
+        # counts live on the host; the device copy is only made (and passed to the kernel) once they stop being uniform
+        self.seg_steps = [0] * len(self.groups)
+        self._seg_step_dev = None
         self._sumsq = torch.zeros(2, dtype=torch.float32, device=device)  # two accumulators alternate: AdamW zeroes the next
         self.return_norm = False  # step() returns the gradient norm tensor (one extra tiny launch) only on request
         if hasattr(model, "mark_weights_dirty"):
@@ -284,13 +291,15 @@ class FusedAdamW(object):
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "opt_step": self.opt_step,
-                "sched_step": self.sched_step, "names": [g[0] for g in self.groups], "row_flags": self.row_flags}
+                "seg_steps": list(self.seg_steps), "sched_step": self.sched_step, "names": [g[0] for g in self.groups],
+                "row_flags": self.row_flags}
 
     def load_state_dict(self, sd):
         assert sd["names"] == [g[0] for g in self.groups], "optimizer state belongs to a different parameter list"
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.opt_step, self.sched_step = int(sd["opt_step"]), int(sd["sched_step"])
+        self.seg_steps = list(sd["seg_steps"]) if sd.get("seg_steps") is not None else [self.opt_step] * len(self.groups)
         self._sumsq.zero_()  # (the accumulator in use alternates with the parity of opt_step)
         if self.row_flags is not None:
             if sd.get("row_flags") is not None:
@@ -411,10 +420,20 @@ class FusedAdamW(object):
         ops.sumsq(a.grad, cur, **(self._flag_args() if self.flag_sumsq else {}))
         norm = (cur.sqrt() * post) if self.return_norm else None
         self.opt_step += 1
+        uniform = True
+        for i, act in enumerate(active):
+            if act:
+                self.seg_steps[i] += 1
+                uniform = uniform and self.seg_steps[i] == self.opt_step
+        seg_step = None
+        if not uniform:  # (rare: a second task head, a parameter that joins late)
+            self._seg_step_dev = torch.tensor(self.seg_steps, dtype=torch.int64).to(a.param.device)
+            seg_step = self._seg_step_dev
         max_norm = self.max_grad_norm if self.max_grad_norm is not None else float("inf")
         ops.adamw(a.param, a.grad, self.exp_avg, self.exp_avg_sq, self.seg_end, self.seg_lr, self.seg_wd,
                   self.betas[0], self.betas[1], self.eps, self.opt_step, self.correct_bias, self.lr_mult(),
-                  sumsq=cur, max_norm=min(max_norm, 3.0e38), post=post, sumsq_next=nxt, zero_grad=True, **self._flag_args())
+                  sumsq=cur, max_norm=min(max_norm, 3.0e38), post=post, sumsq_next=nxt, zero_grad=True, seg_step=seg_step,
+                  **self._flag_args())
         self.sched_step += 1
         if hasattr(self.model, "mark_weights_dirty"):
             self.model.mark_weights_dirty()

@@ -45,8 +45,9 @@ class GQALossFunction(torch.autograd.Function):
         ws = torch.empty(_lib.lib().vl_gqa_loss_ws_bytes(B), dtype=torch.uint8, device=logits.device)
         ops.gqa_loss(logits, target.contiguous().float(), distances.contiguous().float(), semantic_lambda, out, dlogits, ws)
         ctx.save_for_backward(dlogits)
-        ctx.mark_non_differentiable(out[1])
-        return out[0], out[1]
+        loss, score = out[0], out[1]  # bind the views once: the mark has to be on the object that is returned
+        ctx.mark_non_differentiable(score)
+        return loss, score
 
     @staticmethod
     def backward(ctx, g_loss, g_score):

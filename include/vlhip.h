@@ -122,6 +122,16 @@ int vl_dw_grouped_rowmajor(const int64_t* probs, int64_t nprob, int64_t rows, in
  * partials) works in every mode.  A transposing read moves half the bytes of a plain one per LDS instruction, so per
  * K-tile and wave the fragment reads are 24 (mode 0), 32 (mode 2), 40 (mode 1), 48 (mode 3) instructions. */
 int vl_dw_grouped_mixed(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, int mode, void* stream);
+/* Stream-K form of the same launch: a FIXED `budget` of workgroups (= CUs; <= 256) each walks an equal contiguous share of
+ * the launch's {tile} x {64-row K-tile} iterations, so the weight gradients occupy `budget` CUs for the whole launch and
+ * the kernels of the other stream keep the rest (autograd's grad_weight products, volta/encoders.py:229-246, 411-414,
+ * 496-501, 553-556, run beside the dX products instead of fighting them for CUs).  A tile cut by a share boundary is
+ * finished by the workgroup that starts it, from the partial tiles the others leave in `ws`
+ * (vl_dw_streamk_ws_bytes(budget) bytes, caller-owned, ZERO-FILLED once; launches sharing it must be stream-ordered).
+ * Deterministic for a given budget; differs from vl_dw_grouped_mixed by fp32 re-association only. */
+int64_t vl_dw_streamk_ws_bytes(int64_t budget);
+int vl_dw_grouped_streamk(const int64_t* probs, int64_t nprob, int64_t rows, int accumulate, int mode, int64_t budget,
+                          void* ws, int64_t ws_bytes, void* stream);
 /* Up to 8 column reductions in one launch: `tab` = HOST array of n x VL_CR_FIELDS int64 {src [nrows, ncols] fp32, nrows,
  * ncols, seg, out0, out1, out2, 0}: out_t[c] (+)= sum_rows src[row][t*seg + c] for the ncols / seg <= 3 segments (a
  * zero out_t skips a segment).  Deterministic.  Used per layer for the LayerNorm partials of vl_ln_bwd (dgamma, dbeta,
@@ -274,6 +284,9 @@ enum {
                              in the pooled-row mode) is a multiple of 64; 0 = both sides through the re-layout pass */
   VL_ST_DX_TILE = 35, /* tile selection (VL_GX_TILE) of the single-pass products of backward: low byte for N <= 1024, next byte
                          for the wider ones; 0 = automatic */
+  VL_ST_DW_BUDGET = 36, /* > 0: the weight-gradient GEMMs run in the stream-K form on this many workgroups (vl_dw_grouped_streamk) */
+  VL_ST_DW_SK_WS = 37,  /* its workspace (device pointer, zero-filled once) and size in bytes */
+  VL_ST_DW_SK_WS_BYTES = 38,
   VL_ST_FIELDS = 40
 };
 enum {
@@ -470,10 +483,13 @@ int vl_gqa_loss(const float* logits, const float* target, const float* distances
  * is applied (8 B/param of traffic instead of 32; bit-identical to the dense update).
  * A NEGATIVE seg_lr marks a segment whose parameter received no gradient: it is skipped entirely (no moment decay, no
  * weight decay, no memory traffic), like `if p.grad is None: continue` in pytorch_transformers.AdamW.
+ * seg_step (may be NULL): DEVICE array of nseg 1-based per-segment step counts for the bias correction -- the reference
+ * optimizer keeps state['step'] per parameter and advances it only on steps where that parameter has a gradient; NULL =
+ * every segment is at `step`.
  * ------------------------------------------------------------------------------------------------------------ */
 int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const int64_t* seg_end,
              const float* seg_lr, const float* seg_wd, int64_t nseg, float beta1, float beta2, float eps,
-             int64_t step, int correct_bias, float lr_mult, const float* grad_scale_dev, float grad_scale,
+             int64_t step, const int64_t* seg_step, int correct_bias, float lr_mult, const float* grad_scale_dev, float grad_scale,
              const float* sumsq_dev, float max_norm, float post, float* sumsq_next,
              int zero_grad, const uint8_t* row_flags, int64_t flag_begin, int64_t flag_rows, int64_t flag_row_len,
              void* stream);

@@ -791,6 +791,61 @@ def test_gqa_loss_kernel_matches_the_reference_arithmetic(B, C):
     torch.testing.assert_close(dl.double(), z.grad, rtol=2e-5, atol=2e-5 * z.grad.abs().max().item())
 
 
+def test_gqa_loss_with_non_finite_logits_yields_nan_without_leaving_the_row():
+    """A diverged step (a NaN logit, or a row of -inf) must reach the loss as NaN like the reference's eager arithmetic
+    (task_utils.py:413-428) -- never as an out-of-range index: the arg-max sentinels used to be dereferenced unguarded."""
+    B, C = 6, 1842
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(B, C, generator=g).to(DEV)
+    logits[1, 77] = float("nan")
+    logits[3, :] = float("-inf")
+    logits[4, :] = float("nan")
+    target = torch.zeros(B, C, device=DEV)
+    target[torch.arange(B), torch.arange(B) * 3] = 1.0
+    dist = torch.rand(B, C, generator=g).to(DEV)
+    out = torch.zeros(2, device=DEV)
+    dl = torch.zeros(B, C, device=DEV)
+    ws = torch.empty(ops._lib.lib().vl_gqa_loss_ws_bytes(B), dtype=torch.uint8, device=DEV)
+    ops.gqa_loss(logits, target, dist, 10.0, out, dl, ws)
+    torch.cuda.synchronize()
+    assert math.isnan(out[0].item())
+    assert torch.isfinite(dl[[0, 2, 5]]).all()          # the healthy rows keep finite gradients
+    assert torch.isnan(dl[1]).all() and torch.isnan(dl[3]).all() and torch.isnan(dl[4]).all()
+    # and the healthy part is what a batch without the bad rows gives (the row terms are independent)
+    good = [0, 2, 5]
+    out2, dl2 = torch.zeros(2, device=DEV), torch.zeros(3, C, device=DEV)
+    ops.gqa_loss(logits[good].contiguous(), target[good].contiguous(), dist[good].contiguous(), 10.0, out2, dl2, ws)
+    torch.testing.assert_close(dl[good] * (B / 3.0), dl2, rtol=1e-6, atol=1e-7)
+
+
+def test_adamw_per_segment_step_counts():
+    """seg_step: a segment that first received a gradient later than the others is bias-corrected with ITS step count
+    (pytorch_transformers.AdamW keeps state['step'] per parameter; oracle/adamw_oracle.py restates that)."""
+    n = 4096
+    p0, g = _rand(n, seed=61), _rand(n, seed=62)
+    seg_end = torch.tensor([1024, 4096], dtype=torch.int64, device=DEV)
+    seg_lr = torch.tensor([4e-5, 1e-4], device=DEV)
+    seg_wd = torch.tensor([1e-4, 0.0], device=DEV)
+    b1, b2, eps = 0.9, 0.999, 1e-6
+    m0, v0 = _rand(n, seed=63) * 0.1, _rand(n, seed=64).abs() * 0.01
+    p, m, v = p0.clone(), m0.clone(), v0.clone()
+    steps = torch.tensor([7, 2], dtype=torch.int64, device=DEV)
+    ops.adamw(p, g.clone(), m, v, seg_end, seg_lr, seg_wd, b1, b2, eps, 7, True, 1.0, None, 1.0, False, seg_step=steps)
+    for (lo, hi, t, lr, wd) in ((0, 1024, 7, 4e-5, 1e-4), (1024, 4096, 2, 1e-4, 0.0)):
+        q, mm, vv = p0[lo:hi].clone(), m0[lo:hi].clone(), v0[lo:hi].clone()
+        # the same kernel with a uniform step on that slice alone is the reference for the slice
+        ops.adamw(q, g[lo:hi].clone(), mm, vv, torch.tensor([hi - lo], dtype=torch.int64, device=DEV),
+                  torch.tensor([lr], device=DEV), torch.tensor([wd], device=DEV), b1, b2, eps, t, True, 1.0, None, 1.0, False)
+        assert torch.equal(p[lo:hi], q) and torch.equal(m[lo:hi], mm) and torch.equal(v[lo:hi], vv)
+    # and a uniform seg_step array changes nothing against the scalar step
+    pa, ma, va = p0.clone(), m0.clone(), v0.clone()
+    pb, mb, vb = p0.clone(), m0.clone(), v0.clone()
+    ops.adamw(pa, g.clone(), ma, va, seg_end, seg_lr, seg_wd, b1, b2, eps, 5, True, 1.0, None, 1.0, False)
+    ops.adamw(pb, g.clone(), mb, vb, seg_end, seg_lr, seg_wd, b1, b2, eps, 5, True, 1.0, None, 1.0, False,
+              seg_step=torch.tensor([5, 5], dtype=torch.int64, device=DEV))
+    assert torch.equal(pa, pb)
+
+
 def test_qkv_attention_entry_points_equal_the_two_step_sequence():
     """vl_qkv_attention_fwd / _bwd == projection GEMM (split epilogue) + attention, and attention backward +
     dX GEMM, bit for bit; and fp32-grade against fp64 math."""
