@@ -255,6 +255,10 @@ def main():
         model.engine.stack.dw_rowmajor = int(os.environ["BENCH_DW_ROWMAJOR"])
     if os.environ.get("BENCH_DX_TILE"):  # A/B: tile selection of the N = 768 single-pass products of backward
         model.engine.stack.dx_tile = int(os.environ["BENCH_DX_TILE"])
+    if os.environ.get("BENCH_DW_BUDGET"):  # A/B: stream-K weight-gradient GEMMs on this many workgroups (0 = a workgroup per tile)
+        model.engine.stack.dw_budget = int(os.environ["BENCH_DW_BUDGET"])
+    if os.environ.get("BENCH_GEMM_PERSIST"):  # A/B: persistent ping-pong GEMM, "fwd,bwd" workgroup counts (0 = tile per workgroup)
+        model.engine.stack.gemm_persist = tuple(int(x) for x in os.environ["BENCH_GEMM_PERSIST"].split(","))
     if os.environ.get("BENCH_FUSE_IMAGES"):  # A/B: K-major images by GEMM epilogues (bit 0: h, bit 1: du); 0 = re-layout
         model.engine.stack.fuse_images = int(os.environ["BENCH_FUSE_IMAGES"])
     if os.environ.get("BENCH_TR_BWD_LAYERS"):  # A/B: K-major X images of the bottom n layers written in backward

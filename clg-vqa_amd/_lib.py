@@ -37,6 +37,8 @@ _SIGS = {
     "vl_dw_grouped": (c_int, [P, c_int64, c_int64, c_int, P]),
     "vl_dw_grouped_rowmajor": (c_int, [P, c_int64, c_int64, c_int, P]),
     "vl_dw_grouped_mixed": (c_int, [P, c_int64, c_int64, c_int, c_int, P]),
+    "vl_dw_streamk_ws_bytes": (c_int64, [c_int64]),
+    "vl_dw_grouped_streamk": (c_int, [P, c_int64, c_int64, c_int, c_int, c_int64, P, c_int64, P]),
     "vl_colreduce_multi": (c_int, [P, c_int64, c_int, P]),
     "vl_qkv_attention_fwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float,
                                      c_uint64, P]),

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   constexpr int AH = 128, BH = 128;            // rows per half-tile
   constexpr int OFF_A1 = AH * 128, OFF_B0 = 2 * AH * 128, OFF_B1 = OFF_B0 + BH * 128, STAGE = OFF_B1 + BH * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave / WC, wc = wave % WC;
   const bool late = wave >= 4;
@@ -262,9 +262,14 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     it = (long)swz * nk_tile; it_end = it + nk_tile;
   }
   const unsigned smem_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const int frow = lane & 15, fk = lane >> 4;
 
  while (it < it_end) {  // segments (SK = false: exactly one, the whole tile)
+  // (the lane index is laundered per segment, and again behind the K loop: per-lane address arithmetic is then recomputed
+  // where it is used instead of being hoisted out of the segment loop and kept alive across the K loop, which has no
+  // register to spare)
+  int lane = tid & 63;
+  if (SK) asm volatile("" : "+v"(lane));
+  const int frow = lane & 15, fk = lane >> 4;
   const int tile_id = SK ? (int)(it / nk_tile) : swz;
   const int k0 = SK ? (int)(it - (long)tile_id * nk_tile) : 0;
   const int nk = SK ? (int)((it_end - it) < (long)(nk_tile - k0) ? (it_end - it) : (long)(nk_tile - k0)) : nk_tile;
@@ -303,11 +308,15 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
   const long kstep[2] = {P.ka * 2, P.kb * 2};  // bytes
   const char* const obase[2] = {(const char*)P.a + (long)k0 * kstep[0], (const char*)P.b + (long)k0 * kstep[1]};
   constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
+// (SK: the 32-bit per-lane offsets are laundered at every use, so the compiler keeps them as 8 registers instead of 8
+// loop-invariant zero-extended 64-bit pairs)
 #define DW_ISSUE(x, kt)                                                                                          \
   do {                                                                                                           \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(obase[(x) >> 1] + (long)(kt) * kstep[(x) >> 1] + soff[x][0]),   \
+    unsigned o0_ = soff[x][0], o1_ = soff[x][1];                                                                 \
+    if (SK) { asm volatile("" : "+v"(o0_)); asm volatile("" : "+v"(o1_)); }                                      \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(obase[(x) >> 1] + (long)(kt) * kstep[(x) >> 1] + o0_),          \
                                      (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + wave * 1024), 16, 0, 0);  \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(obase[(x) >> 1] + (long)(kt) * kstep[(x) >> 1] + soff[x][1]),   \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(obase[(x) >> 1] + (long)(kt) * kstep[(x) >> 1] + o1_),          \
                                      (lds_ptr_t)(smem + ((kt) & 1) * STAGE + XOFF[x] + (wave + 8) * 1024), 16, 0, 0); \
   } while (0)
 #define DW_WAIT(issued)                                                                                          \
@@ -358,11 +367,15 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 
   // fa[0]: A fragments of quadrant row 0 -- rows i >= MI / 2 are read one phase EARLY (in the otherwise read-free last
   // phase of the previous K-tile), which levels the LDS reads of the four phases from 12 / 4 / 8 / 0 to 8 / 4 / 8 / 4 fragments
-  bf16x8 fa[2][MI][2], fb0[NJ][2], fb1[NJ][2];
+  // (LEVEL = false, the stream-K form: one fragment set for both quadrant rows and no early half -- the segment loop
+  // around the K loop leaves no room for the second set; the levelling is worth ~2 % of the kernel)
+  constexpr bool LEVEL = !SK;
+  constexpr int FQ = LEVEL ? 1 : 0;  // fa[qm * FQ]
+  bf16x8 fa[LEVEL ? 2 : 1][MI][2], fb0[NJ][2], fb1[NJ][2];
 #define DW_READ_A(st, qm, i0, i1)                                                                                \
   _Pragma("unroll") for (int i = (i0); i < (i1); ++i) {                                                         \
-    fa[qm][i][0] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][0]);                                                        \
-    fa[qm][i][1] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][1]);                                                        \
+    fa[(qm) * FQ][i][0] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][0]);                                                 \
+    fa[(qm) * FQ][i][1] = dw_frag<TA, (qm) * OFF_A1>(a_o[i][1]);                                                 \
   }
 #define DW_READ_B(st, qn, fb)                                                                                    \
   _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     if (bias_now) {                                                                                              \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
       _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                              \
-      _Pragma("unroll") for (int i = 0; i < MI; ++i) frag_dot(bsum[qm][i], fa[qm][i][kk], t, 0x3F803F80u);           \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) frag_dot(bsum[qm][i], fa[(qm) * FQ][i][kk], t, 0x3F803F80u);           \
     }                                                                                                            \
   } while (0)
 #define DW_MFMA(qm, qn, fb)                                                                                \
@@ -388,7 +401,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                             \
     _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                             \
       _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
-        acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[qm][i][kk], acc[qm][qn][i][j], 0, 0, 0); \
+        acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][kk], fa[(qm) * FQ][i][kk], acc[qm][qn][i][j], 0, 0, 0); \
     }                                                                                                            \
     __builtin_amdgcn_s_setprio(0);                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -404,7 +417,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
-  DW_READ_A(st, 0, MI / 2, MI);            // K-tile 0's early half
+  if (LEVEL) DW_READ_A(st, 0, MI / 2, MI);  // K-tile 0's early half
   if (late) __builtin_amdgcn_s_barrier();  // stagger
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -413,7 +426,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     const bool bias_now = bias_wave && ((k0 + kt) % P.tiles_n) == tn;
     DW_READ_B(st, 0, fb0);
     __builtin_amdgcn_sched_barrier(0);
-    DW_READ_A(st, 0, 0, MI / 2);
+    DW_READ_A(st, 0, 0, LEVEL ? MI / 2 : MI);
     if (n1) DW_ISSUE(3, kt + 1);
     DW_WAIT(n1);
     DW_MFMA(0, 0, fb0);
@@ -432,7 +445,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
     DW_MFMA(1, 1, fb1);
     // (A0 of K-tile kt + 1 landed with the wait of the previous phase and is visible after its barriers; the fragment
     // addresses already point to that stage)
-    DW_READ_A(st, 0, MI / 2, MI);
+    if (LEVEL) DW_READ_A(st, 0, MI / 2, MI);
     if (n2) DW_ISSUE(2, kt + 2);
     DW_WAIT(n2);
     DW_MFMA(1, 0, fb0);
@@ -447,10 +460,14 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
 #undef DW_BIAS
 
   if (SK) {
+    lane = tid & 63;
+    asm volatile("" : "+v"(lane));
+  }
+  if (SK) {
     if (k0 != 0) {
       // contributor: raw accumulators (+ bias partial sums) -> this workgroup's slot, then the flag.  Register r of
       // thread tid at float4 index r * 512 + tid: every store instruction of a wave is one contiguous KB
-      float4* slot = reinterpret_cast<float4*>(ga.sk_slots + (long)swz * SK_SLOT_FLOATS) + tid;
+      float4* slot = reinterpret_cast<float4*>(ga.sk_slots + (long)swz * SK_SLOT_FLOATS) + (wave * 64 + lane);
 #pragma unroll
       for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -483,7 +500,7 @@ __global__ __launch_bounds__(512) void dw_grouped_kernel(DwArgs ga) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();
-      const float4* slot = reinterpret_cast<const float4*>(ga.sk_slots + (long)c * SK_SLOT_FLOATS) + tid;
+      const float4* slot = reinterpret_cast<const float4*>(ga.sk_slots + (long)c * SK_SLOT_FLOATS) + (wave * 64 + lane);
       // (two halves of 16 loads each, fenced: all 32 in flight at once would need 128 more registers than there are)
 #pragma unroll
       for (int qm = 0; qm < 2; ++qm) {

@@ -59,6 +59,7 @@ struct GemmArgs {
   int k_len; long slab_stride;  // split-K: blockIdx.y owns k in [y*k_len, (y+1)*k_len) and writes slab y of out32
   int tile;                     // host-side kernel / tile selection (see above); not read by the kernels
   float* ws; long ws_floats;    // host-side: caller-owned workspace of the small-M path (may be NULL)
+  int persist;                  // host-side: > 0 = ping-pong kernel in its persistent form on this many workgroups
   // 16-bit epilogues: additionally store out_hi in the K-major blocked layout of the weight-gradient GEMM
   // (img[((m >> 6) * img_n + n) * 64 + (m & 63)], dw.hip) -- the producer writes the image, no re-layout pass reads the
   // row-major copy back; cs (ping-pong kernel only): fp32 column sums of the rounded out_hi values per (tile, M half,
@@ -461,7 +462,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 }
 
-template <int NSPLIT, int EPI, int CFG>
+// PERSIST: the grid is a fixed number of workgroups G (<= the CU count); workgroup w runs tiles w, w + G, w + 2G, ... (the
+// XCD-contiguous tile order is kept: tile t and t + G land on the same XCD when G % 8 == 0).  Between two tiles the DMA
+// prologue of the NEXT tile (K-tile 0 + A0 / B0 of K-tile 1) is issued right behind the last MFMA section, BEFORE the
+// epilogue of the finished tile: its HBM latency hides under the epilogue's arithmetic, and the epilogue's stores drain
+// under the next tile's first MFMA sections instead of in front of an idle matrix pipe (with one tile per workgroup all
+// 256 CUs reach their epilogues together: a burst of 64 MB of stores, then a burst of first loads, per round).  Counted
+// vmcnt waits stay valid with the younger stores in flight: loads return in order among themselves, so "at most N
+// outstanding" still implies that everything older than the N youngest LOADS has landed (stores only make the wait
+// stricter).
+template <int NSPLIT, int EPI, int CFG, bool PERSIST>
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   constexpr int WR = CFG == 1 ? 4 : 2, WC = 8 / WR;        // wave grid
   constexpr int MI = CFG == 1 ? 2 : 4, NJ = CFG == 1 ? 3 : 2;  // 16 x 16 MFMA tiles per quadrant (first M half)
@@ -481,36 +491,39 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   const bool late = wave >= 4;  // the wave group that runs one barrier behind
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-  const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = swz / p.tiles_n, tn = swz - tm * p.tiles_n;
-  const int row0 = tm * BMT, col0 = tn * BNT;
   const int nk = p.K / KSTEP;
-
+  const int q8 = nwg >> 3, r8 = nwg & 7;
+  int row0, col0, tm;
   // DMA sources: half-tile x in {A0, A1, B0, B1}; unit u = wave + 8*j (8 rows x 128 B); lane -> (row, physical chunk)
   const bf16_raw* src[4][2];
+  auto set_tile = [&](int t) {  // tile index in dispatch order -> (row0, col0), per-lane DMA source pointers
+    const int xcd = t & 7;
+    const int swz = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (t >> 3);
+    tm = swz / p.tiles_n;
+    const int tn = swz - tm * p.tiles_n;
+    row0 = tm * BMT; col0 = tn * BNT;
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+    for (int x = 0; x < 4; ++x)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const bool isB = x >= 2;
-      const int r = 8 * (wave + 8 * j) + (lane >> 3);
-      const int lc = (lane & 7) ^ swz3(r);  // logical chunk that lands at physical position lane & 7
-      int g = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + r;
-      const int lim = (isB ? p.N : p.M) - 1;
-      g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
-      const bf16_raw* base;
-      int koff;
-      if (NSPLIT == 3) {
-        base = isB ? ((lc & 4) ? p.b_lo : p.b_hi) : ((lc & 4) ? p.a_lo : p.a_hi);
-        koff = (lc & 3) * 8;
-      } else {
-        base = isB ? p.b_hi : p.a_hi;
-        koff = lc * 8;
+      for (int j = 0; j < 2; ++j) {
+        const bool isB = x >= 2;
+        const int r = 8 * (wave + 8 * j) + (lane >> 3);
+        const int lc = (lane & 7) ^ swz3(r);  // logical chunk that lands at physical position lane & 7
+        int g = (isB ? col0 + (x & 1) * BH : row0 + (x & 1) * AH) + r;
+        const int lim = (isB ? p.N : p.M) - 1;
+        g = g < lim ? g : lim;  // rows past the edge re-read a valid row; their products are never stored
+        const bf16_raw* base;
+        int koff;
+        if (NSPLIT == 3) {
+          base = isB ? ((lc & 4) ? p.b_lo : p.b_hi) : ((lc & 4) ? p.a_lo : p.a_hi);
+          koff = (lc & 3) * 8;
+        } else {
+          base = isB ? p.b_hi : p.a_hi;
+          koff = lc * 8;
+        }
+        src[x][j] = base + (long)g * (isB ? p.ldb : p.lda) + koff;
       }
-      src[x][j] = base + (long)g * (isB ? p.ldb : p.lda) + koff;
-    }
+  };
   constexpr int XOFF[4] = {0, OFF_A1, OFF_B0, OFF_B1};
 #define G3_ISSUE(x, kt)                                                                                          \
   do {                                                                                                           \
@@ -533,14 +546,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   } while (0)
 
   f32x4 acc[2][2][MI][NJ];  // [1][*][i >= MI1] unused
-#pragma unroll
-  for (int a_ = 0; a_ < 2; ++a_)
-#pragma unroll
-    for (int b_ = 0; b_ < 2; ++b_)
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment byte offsets inside a half-tile: [tile][first / second 64-B half of the row], swizzle folded in
   const int frow = lane & 15, fk = lane >> 4;
@@ -602,16 +607,32 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   } while (0)
 
   // prologue: K-tile 0 complete, A0 / B0 of K-tile 1 in flight
-  G3_ISSUE(0, 0); G3_ISSUE(2, 0); G3_ISSUE(3, 0); G3_ISSUE(1, 0);
-  if (nk > 1) {
-    G3_ISSUE(0, 1); G3_ISSUE(2, 1);
-    G3_WAIT_YOUNGER(1, 1);
-  } else {
-    wait_vmcnt<0>();
-  }
-  __builtin_amdgcn_s_barrier();
-  if (late) __builtin_amdgcn_s_barrier();  // stagger
+#define G3_PROLOGUE_ISSUE()                                                                                      \
+  do {                                                                                                           \
+    G3_ISSUE(0, 0); G3_ISSUE(2, 0); G3_ISSUE(3, 0); G3_ISSUE(1, 0);                                              \
+    if (nk > 1) { G3_ISSUE(0, 1); G3_ISSUE(2, 1); }                                                              \
+  } while (0)
+#define G3_PROLOGUE_WAIT()                                                                                       \
+  do {                                                                                                           \
+    if (nk > 1) G3_WAIT_YOUNGER(1, 1);                                                                           \
+    else wait_vmcnt<0>();                                                                                        \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    if (late) __builtin_amdgcn_s_barrier(); /* stagger */                                                        \
+  } while (0)
+  set_tile(blockIdx.x);
+  G3_PROLOGUE_ISSUE();
+  G3_PROLOGUE_WAIT();
 
+ int t = blockIdx.x;
+ do {  // tiles of this workgroup (exactly one unless PERSIST)
+#pragma unroll
+  for (int a_ = 0; a_ < 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < 2; ++b_)
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
@@ -638,14 +659,19 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     G3_MFMA(1, 0, fb0);
   }
   if (!late) __builtin_amdgcn_s_barrier();  // matches the stagger barrier
-#undef G3_ISSUE
-#undef G3_WAIT_YOUNGER
-#undef G3_WAIT
-#undef G3_READ_A
-#undef G3_READ_B
-#undef G3_MFMA
+  // the finished tile's coordinates for the epilogue; then (PERSIST) the next tile's DMA prologue goes out first
+  const int e_row0 = row0, e_col0 = col0, e_tm = tm;
+  const bool has_next = PERSIST && t + (int)gridDim.x < nwg;
+  if (has_next) {
+    set_tile(t + (int)gridDim.x);
+    G3_PROLOGUE_ISSUE();
+  }
 
   // epilogue.  D^T layout: lane&15 -> m inside the 16-row tile, 4*(lane>>4) + reg -> n inside the 16-col tile
+  // (PERSIST: the lane index is laundered, so the per-lane address arithmetic of the epilogue is computed here instead of
+  // being hoisted out of the tile loop and kept alive across the K loop, which has no register to spare)
+  int lane_e = lane;
+  if (PERSIST) asm volatile("" : "+v"(lane_e));
   float* out32 = p.out32;
   // K-major image of out_hi: a wave stages its [MI*16 rows] x [2 x NJ*16 columns] part of an M half column-major in a
   // private LDS region (the K loop is over, LDS is free; 2-byte ds_writes, pitch rows*2 + 8 B: conflict-free), then
@@ -673,17 +699,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
         for (int t = 0; t < 4; ++t) csum[qn][j][t] = 0.f;
 #pragma unroll
     for (int i = 0; i < (qm == 0 ? MI : MI1); ++i) {
-      const int m = row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane & 15);
+      const int m = e_row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane_e & 15);
       const bool row_ok = m < p.M;
-      bf16_raw* lrow = use_limg ? reinterpret_cast<bf16_raw*>(limg) + i * 16 + (lane & 15) : nullptr;
+      bf16_raw* lrow = use_limg ? reinterpret_cast<bf16_raw*>(limg) + i * 16 + (lane_e & 15) : nullptr;
 #pragma unroll
       for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int cb = col0 + qn * BH + wc * (NJ * 16);
+          const int cb = e_col0 + qn * BH + wc * (NJ * 16);
           if (j < NJP) {
             if ((j & 1) == 0) {
-              const int nl = 32 * (j >> 1) + 8 * (lane >> 4);  // column inside the wave's NJ*16-wide span
+              const int nl = 32 * (j >> 1) + 8 * (lane_e >> 4);  // column inside the wave's NJ*16-wide span
               const int n0 = cb + nl;
               if (row_ok && n0 < p.N)
                 epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j], want_cs,
@@ -691,7 +717,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
                                      lrow ? lrow + (qn * NJ * 16 + nl) * IMG_LP : nullptr, IMG_LP);
             }
           } else {
-            const int nl = j * 16 + 4 * (lane >> 4);
+            const int nl = j * 16 + 4 * (lane_e >> 4);
             const int n0 = cb + nl;
             if (row_ok && n0 < p.N)
               epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j], want_cs, csum[qn][j],
@@ -702,11 +728,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     if (EPI != VL_EPI_F32 && use_limg) {  // flush the staged part: 16-byte chunks of 8 consecutive rows of one column
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       constexpr int ROWS = (qm == 0 ? MI : MI1) * 16, CPC = ROWS / 8;
-      const int mbase = row0 + qm * AH + wr * ROWS;
-      for (int idx = lane; idx < IMG_NCOL * CPC; idx += 64) {
+      const int mbase = e_row0 + qm * AH + wr * ROWS;
+      for (int idx = lane_e; idx < IMG_NCOL * CPC; idx += 64) {
         const int nl = idx / CPC, c = idx - nl * CPC;
         const int qn = nl / (NJ * 16);
-        const int n = col0 + qn * BH + wc * (NJ * 16) + (nl - qn * (NJ * 16));
+        const int n = e_col0 + qn * BH + wc * (NJ * 16) + (nl - qn * (NJ * 16));
         const int m8 = mbase + c * 8;
         if (n < p.N && m8 < p.M) {
           const unsigned char* src = limg + nl * IMG_PITCH + c * 16;
@@ -718,7 +744,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (EPI == VL_EPI_DGELU_BF16 && want_cs) {  // one partial row per (tile row, M half, wave row): sum over the 16 row lanes, then store
-      float* dst = p.cs + (long)((tm * 2 + qm) * WR + wr) * p.N;
+      float* dst = p.cs + (long)((e_tm * 2 + qm) * WR + wr) * p.N;
 #pragma unroll
       for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
@@ -730,10 +756,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
             x += __shfl_xor(x, 1); x += __shfl_xor(x, 2); x += __shfl_xor(x, 4); x += __shfl_xor(x, 8);
             v[t] = x;
           }
-          if ((lane & 15) == 0) {
-            const int cb = col0 + qn * BH + wc * (NJ * 16);
-            // paired tiles (j, j+1): csum[j] = columns +0..3, csum[j+1] = columns +4..7 of the lane's 8-column group
-            const int n0 = j < NJP ? cb + 32 * (j >> 1) + 8 * (lane >> 4) + 4 * (j & 1) : cb + j * 16 + 4 * (lane >> 4);
+          if ((lane_e & 15) == 0) {
+            const int cb = e_col0 + qn * BH + wc * (NJ * 16);
+            // paired tiles (j, j+1): csum[j] = columns +0..3, csum[j+1] = columns +4..7 of the lane_e's 8-column group
+            const int n0 = j < NJP ? cb + 32 * (j >> 1) + 8 * (lane_e >> 4) + 4 * (j & 1) : cb + j * 16 + 4 * (lane_e >> 4);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
               if (n0 + t < p.N) dst[n0 + t] = v[t];
@@ -743,6 +769,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   };
   half(std::integral_constant<int, 0>{});
   half(std::integral_constant<int, 1>{});
+  if (has_next) G3_PROLOGUE_WAIT();
+  t += (int)gridDim.x;
+ } while (PERSIST && t < nwg);
+#undef G3_ISSUE
+#undef G3_WAIT_YOUNGER
+#undef G3_WAIT
+#undef G3_READ_A
+#undef G3_READ_B
+#undef G3_MFMA
+#undef G3_PROLOGUE_ISSUE
+#undef G3_PROLOGUE_WAIT
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1175,23 +1212,36 @@ int launch2w(GemmArgs a, hipStream_t stream, int splits) {
   return 0;
 }
 thread_local int tl_cs_rows = 0;  // scratch of one vl_gemm_nt_ex call (reported through VL_GX_COLSUM_ROWS)
-template <int NSPLIT, int EPI, int CFG>
-int launch3(GemmArgs a, hipStream_t stream) {
-  constexpr int BMT = CFG == 2 ? 224 : 256, BNT = CFG == 1 ? 192 : 256;
-  const size_t lds = 2 * (BMT + BNT) * 128;
+template <int NSPLIT, int EPI, int CFG, bool PERSIST>
+int launch3p(const GemmArgs& a, int grid, size_t lds, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, CFG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel<NSPLIT, EPI, CFG, PERSIST>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return vl_set_error(-3, "vl_gemm_nt: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
+  hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, CFG, PERSIST>), dim3(grid), dim3(512), lds, stream, a);
+  VL_CHECK_LAUNCH("vl_gemm_nt(ping-pong)");
+  return 0;
+}
+template <int NSPLIT, int EPI, int CFG>
+int launch3(GemmArgs a, hipStream_t stream) {
+  constexpr int BMT = CFG == 2 ? 224 : 256, BNT = CFG == 1 ? 192 : 256;
+  const size_t lds = 2 * (BMT + BNT) * 128;
   a.tiles_m = (a.M + BMT - 1) / BMT;
   a.tiles_n = (a.N + BNT - 1) / BNT;
   tl_cs_rows = a.tiles_m * 2 * (CFG == 1 ? 4 : 2);  // column-sum partial rows this configuration writes
-  hipLaunchKernelGGL((gemm3_kernel<NSPLIT, EPI, CFG>), dim3(a.tiles_m * a.tiles_n), dim3(512), lds, stream, a);
-  VL_CHECK_LAUNCH("vl_gemm_nt(ping-pong)");
-  return 0;
+  const int tiles = a.tiles_m * a.tiles_n;
+  // persistent form (VL_GX_PERSIST): instantiated for the epilogues the layer stack uses; it stages nothing through
+  // LDS in its epilogue, so the K-major image / column-sum options keep the one-tile-per-workgroup form
+  constexpr bool kPersistable = (NSPLIT == 3 && (EPI == VL_EPI_F32 || EPI == VL_EPI_SPLIT || EPI == VL_EPI_GELU_SPLIT)) ||
+                                (NSPLIT == 1 && (EPI == VL_EPI_F32 || EPI == VL_EPI_DGELU_BF16 || EPI == VL_EPI_BF16));
+  if constexpr (kPersistable) {
+    if (a.persist > 0 && tiles > a.persist && !a.img && !a.cs)
+      return launch3p<NSPLIT, EPI, CFG, true>(a, a.persist, lds, stream);
+  }
+  return launch3p<NSPLIT, EPI, CFG, false>(a, tiles, lds, stream);
 }
 template <int NSPLIT, int EPI, int BN>
 int launch2(const GemmArgs& a, hipStream_t stream, int splits) {
@@ -1294,6 +1344,8 @@ extern "C" int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, co
                              const float* bias, const float* resid32, float* out32, int64_t ldc, void* out_hi,
                              void* out_lo, void* aux16, int64_t ld16, int64_t* extra, void* stream) {
   const int tile = extra ? (int)extra[VL_GX_TILE] : 0;
+  const int64_t persist = extra ? extra[VL_GX_PERSIST] : 0;
+  VL_CHECK_ARG(persist >= 0 && persist <= 1024, "vl_gemm_nt_ex: VL_GX_PERSIST must be in [0, 1024] (got %lld)", (long long)persist);
   float* ws = extra ? reinterpret_cast<float*>(static_cast<uintptr_t>(extra[VL_GX_WS])) : nullptr;
   const int64_t ws_floats = extra ? extra[VL_GX_WS_FLOATS] : 0;
   VL_CHECK_ARG(passes == 1 || passes == 3, "vl_gemm_nt: passes must be 1 or 3 (got %d)", passes);
@@ -1324,7 +1376,7 @@ extern "C" int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, co
   a.bias = bias; a.resid = resid32; a.out32 = out32; a.ldc = ldc;
   a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.aux16 = (bf16_raw*)aux16; a.ld16 = ld16;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
-  a.k_len = (int)K; a.slab_stride = 0; a.tile = tile;
+  a.k_len = (int)K; a.slab_stride = 0; a.tile = tile; a.persist = (int)persist;
   VL_CHECK_ARG(tile != 8 || ws, "vl_gemm_nt_ex: tile 8 (small-M path) needs a workspace");
   VL_CHECK_ARG(!ws || ((reinterpret_cast<uintptr_t>(ws) & 15u) == 0 && ws_floats >= 0), "vl_gemm_nt_ex: workspace must be 16-byte aligned");
   a.ws = ws; a.ws_floats = ws_floats;

@@ -50,7 +50,7 @@ void prof_end(int64_t* pair, int64_t tag, int64_t flops, void* stream) {
 
 // vl_gemm_nt, optionally bracketed by a caller-owned event pair (descriptor field VL_ST_PROF); B-row products of the
 // pooled-row mode take the small-M path through the descriptor's workspace (VL_ST_SMALL_WS)
-struct GemmCtx { int64_t* prof; float* ws; int64_t ws_floats; int64_t tile1; };
+struct GemmCtx { int64_t* prof; float* ws; int64_t ws_floats; int64_t tile1; int64_t persist; };
 struct GemmImage { void* img; int64_t cols; float* colsum; int64_t* colsum_rows; };
 int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
          int64_t M, int64_t N, int64_t K, int passes, int epi, const float* bias, const float* resid, float* out32,
@@ -60,6 +60,7 @@ int gemm(const GemmCtx& g, const void* a_hi, const void* a_lo, int64_t lda, cons
   extra[VL_GX_WS] = (int64_t)(uintptr_t)g.ws; extra[VL_GX_WS_FLOATS] = g.ws_floats;
   // (VL_ST_DX_TILE, A/B knob: low byte = tile of the narrow single-pass products, next byte = of the wide one)
   if (passes == 1 && g.tile1 && M >= 2048) extra[VL_GX_TILE] = N <= 1024 ? (g.tile1 & 255) : ((g.tile1 >> 8) & 255);
+  extra[VL_GX_PERSIST] = passes == 3 ? (g.persist & 0xffff) : ((g.persist >> 16) & 0xffff);
   if (im) {
     extra[VL_GX_IMG] = (int64_t)(uintptr_t)im->img; extra[VL_GX_IMG_COLS] = im->cols;
     extra[VL_GX_COLSUM] = (int64_t)(uintptr_t)im->colsum;
@@ -165,7 +166,7 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
   const float* addmask = ptr<const float>(d[VL_ST_ADDMASK]);
   const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
   int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
-  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS], d[VL_ST_DX_TILE]};
+  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS], d[VL_ST_DX_TILE], d[VL_ST_GEMM_PERSIST]};
   hipStream_t ss = stream_side ? (hipStream_t)stream_side : (hipStream_t)stream;
   hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);
   for (int64_t l = layer_begin; l < layer_end; ++l) {
@@ -237,7 +238,7 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
   const float* row_post = ptr<const float>(d[VL_ST_ROW_POST]);
   const int accumulate = (int)d[VL_ST_ACCUMULATE];
   int64_t* prof = ptr<int64_t>(d[VL_ST_PROF]);
-  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS], d[VL_ST_DX_TILE]};
+  const GemmCtx gc{prof, ptr<float>(d[VL_ST_SMALL_WS]), d[VL_ST_SMALL_WS_FLOATS], d[VL_ST_DX_TILE], d[VL_ST_GEMM_PERSIST]};
   hipStream_t sm = (hipStream_t)stream_main;
   hipStream_t ss = stream_side ? (hipStream_t)stream_side : sm;
   hipEvent_t fork = ptr<ihipEvent_t>(d[VL_ST_EV_FORK]);
@@ -318,11 +319,20 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
           a_o, H, bc, H, y[VL_LY_GRAD0 + 6], H, y[VL_LY_MASK0 + 3], H, H, 0,
           a_1, I, b1, H, y[VL_LY_GRAD0 + 10], H, y[VL_LY_MASK0 + 4], I, H, d[VL_ST_CS_U],
           a_2, H, bh, I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
+      // (VL_ST_DW_BUDGET > 0: the stream-K form on a fixed number of workgroups -- the dX products of the main stream
+      // keep the other CUs; launches of the side stream share the workspace in stream order)
+      const int64_t budget = d[VL_ST_DW_BUDGET];
+      void* skws = ptr<void>(d[VL_ST_DW_SK_WS]);
+      auto dw = [&](const int64_t* probs, int64_t n, int64_t rows) {
+        if (budget > 0 && rows >= 1024)
+          return vl_dw_grouped_streamk(probs, n, rows, accumulate, mode, budget, skws, d[VL_ST_DW_SK_WS_BYTES], ss);
+        return vl_dw_grouped_mixed(probs, n, rows, accumulate, mode, ss);
+      };
       if (pooled) {  // Q/K/V gradients reduce over all M rows, the other three over the B live rows
-        VL_TRY(vl_dw_grouped_mixed(pr, 3, M, accumulate, mode, ss));
-        VL_TRY(vl_dw_grouped_mixed(pr + 3 * VL_DW_FIELDS, 3, R, accumulate, mode, ss));
+        VL_TRY(dw(pr, 3, M));
+        VL_TRY(dw(pr + 3 * VL_DW_FIELDS, 3, R));
       } else {
-        VL_TRY(vl_dw_grouped_mixed(pr, 6, M, accumulate, mode, ss));
+        VL_TRY(dw(pr, 6, M));
       }
       const int64_t cr[6 * VL_CR_FIELDS] = {
           y[VL_LY_LNWS2], nws, 3 * H, H, y[VL_LY_GRAD0 + 14], y[VL_LY_GRAD0 + 15], y[VL_LY_GRAD0 + 13], 0,

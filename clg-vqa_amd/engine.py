@@ -286,6 +286,7 @@ class StackArena(object):
             self.cs_qkv, self.cs_u = f32(max(mb, 3 * tq), 3 * H), f32(max(mb, tq), I)
             self.fork = torch.cuda.Event()
             self.fork.record()  # materialises the hipEvent_t behind the handle
+            self.dw_sk_ws = None  # workspace of the stream-K weight-gradient GEMM (LayerStack.dw_budget), made on demand
 
     def lay(self, t, l):
         return t[l if self.need_grad else 0]
@@ -307,6 +308,14 @@ class LayerStack(object):
         # tile of the narrow (N <= 1024) single-pass products of backward: 2 = 256 x 256 (168 workgroups at c2, one round on
         # the CUs the concurrent weight-gradient GEMM leaves free; -0.18 ms / step against the automatic 256 x 192); 0 = automatic
         self.dx_tile = 2
+        # CU budget of the weight-gradient GEMMs: > 0 = stream-K form on that many workgroups (csrc/dw.hip), the dX products
+        # of the main stream keep the remaining CUs (88 + 168 one-round dX products at c2); 0 = one workgroup per 256 x 256
+        # tile (108 per layer at c2)
+        self.dw_budget = 0
+        # persistent form of the ping-pong GEMM (VL_GX_PERSIST): workgroup counts for (forward 3-pass, backward single-pass)
+        # products; 0 = one workgroup per tile.  Measured at c2 (same box, profiles/r03_ab_log.txt): forward 16.09 -> 16.05
+        # ms / step (bit-identical results), backward neutral to negative beside the weight-gradient stream
+        self.gemm_persist = (256, 0)
         # the heads of this path read hidden_states[:, 0] only (BertTextPooler encoders.py:597-608, M3P BertPooler): the
         # last layer then runs on the B live rows after its K/V projection and the stack returns [B, 1, H] (exact: the
         # live rows are bit-identical to the dense run, the dead ones are never computed)
@@ -447,6 +456,15 @@ class LayerStack(object):
         d[VL["VL_ST_FUSE_IMAGES"]] = self.fuse_images
         d[VL["VL_ST_DW_ROWMAJOR"]] = int(self.dw_rowmajor)
         d[VL["VL_ST_DX_TILE"]] = int(self.dx_tile)
+        d[VL["VL_ST_GEMM_PERSIST"]] = int(self.gemm_persist[0]) | (int(self.gemm_persist[1]) << 16)
+        if ar.need_grad and self.dw_budget > 0:
+            if ar.dw_sk_ws is None or ar.dw_sk_budget != self.dw_budget:
+                ar.dw_sk_ws, ar.dw_sk_budget = ops.dw_streamk_ws(self.dw_budget, ar.x32.device), self.dw_budget
+            d[VL["VL_ST_DW_BUDGET"]] = int(self.dw_budget)
+            d[VL["VL_ST_DW_SK_WS"]] = ar.dw_sk_ws.data_ptr()
+            d[VL["VL_ST_DW_SK_WS_BYTES"]] = ar.dw_sk_ws.numel()
+        else:
+            d[VL["VL_ST_DW_BUDGET"]] = 0
         side_ptr = None
         if ar.need_grad and self.overlap_dw:
             dev = ar.x32.device

@@ -76,7 +76,7 @@ def small_ws(device, floats, stream):
 
 
 def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=None, out32=None, out_hi=None,
-            out_lo=None, aux16=None, tile=0, image=None, image_cols=0, colsum=None):
+            out_lo=None, aux16=None, tile=0, image=None, image_cols=0, colsum=None, persist=0):
     """C[M,N] = A[M,K] . B[N,K]^T (+epilogue); operands are bf16 2-D tensors (row-major, ld = stride(0)).  Products
     with a small M (the batch-sized products of the head) get a workspace and take the library's small-M path.
     image / image_cols: also store out_hi as the K-major image of the weight-gradient GEMM; colsum [rows, N] fp32:
@@ -97,6 +97,7 @@ def gemm_nt(a_hi, a_lo, b_hi, b_lo, M, N, K, passes, epilogue, bias=None, resid=
     st = _stream()
     extra = (ctypes.c_int64 * 8)()
     extra[0] = tile
+    extra[7] = persist  # > 0: persistent form of the ping-pong kernel on that many workgroups (VL_GX_PERSIST)
     if M <= 8192 and tile in (0, 8) and colsum is None and (SMALL_GEMM or tile == 8):
         nws = L.vl_gemm_small_ws_floats(M, N, K)
         extra[1], extra[2] = small_ws(a_hi.device, nws, st).data_ptr(), nws
@@ -215,9 +216,10 @@ def dw_grouped_rowmajor(problems, rows, accumulate=False):
                                                  _stream()), "vl_dw_grouped_rowmajor")
 
 
-def dw_grouped_mixed(problems, rows, mode, accumulate=False):
+def dw_grouped_mixed(problems, rows, mode, accumulate=False, budget=0, ws=None):
     """problems = [(a, a_cols, b, b_cols, out, mask, M, N, colsum)]: an operand is a row-major 2-D bf16 view (its *_cols is
-    None) when its mode bit is set (bit 0: dY, bit 1: X), else its K-major image (1-D tensor) with the image's column count."""
+    None) when its mode bit is set (bit 0: dY, bit 1: X), else its K-major image (1-D tensor) with the image's column count.
+    budget > 0: the stream-K form on that many workgroups with the zero-initialised workspace `ws` (dw_streamk_ws)."""
     import ctypes
     n = len(problems)
     arr = (ctypes.c_int64 * (10 * n))()
@@ -226,8 +228,19 @@ def dw_grouped_mixed(problems, rows, mode, accumulate=False):
         pb, ldb = _pld(b) if mode & 2 else (_p(b), b_cols)
         arr[10 * i:10 * i + 10] = [pa, lda, pb, ldb, out.data_ptr(), out.stride(0), 0 if mask is None else _p(mask), M, N,
                                    0 if cs is None else _p(cs)]
+    if budget:
+        _lib.check(_lib.lib().vl_dw_grouped_streamk(ctypes.cast(arr, ctypes.c_void_p), n, rows, 1 if accumulate else 0, mode,
+                                                    int(budget), _p(ws), ws.numel() * ws.element_size(), _stream()),
+                   "vl_dw_grouped_streamk")
+        return
     _lib.check(_lib.lib().vl_dw_grouped_mixed(ctypes.cast(arr, ctypes.c_void_p), n, rows, 1 if accumulate else 0, mode,
                                               _stream()), "vl_dw_grouped_mixed")
+
+
+def dw_streamk_ws(budget, device):
+    """Zero-initialised workspace of the stream-K weight-gradient GEMM for `budget` workgroups (hand-off flags + one
+    partial-tile slot per workgroup); launches that share it must be ordered on one stream."""
+    return torch.zeros(_lib.lib().vl_dw_streamk_ws_bytes(int(budget)), dtype=torch.uint8, device=device)
 
 
 def attn2_fwd(qkv_hi, qkv_lo, addmask, ctx_hi, ctx_lo, lse, B, S, nh, dh, p_drop, seed, nq=None):

@@ -65,9 +65,14 @@ int vl_gemm_nt(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi
  *  VL_GX_COLSUM  (DGELU epilogue, ping-pong kernel only -- vl_gemm_nt_path() == 2) fp32 [rows, N] partial column sums of
  *              the rounded out_hi values, the bias-gradient partials the re-layout pass used to produce; on return
  *              VL_GX_COLSUM_ROWS holds the number of partial rows written (<= 8 * ceil(M / 256)): sum them with
- *              vl_colreduce_multi. */
+ *              vl_colreduce_multi.
+ *  VL_GX_PERSIST  > 0: the ping-pong kernel in its PERSISTENT form on that many workgroups (use the CU count, 256): a
+ *              workgroup runs tiles w, w + G, ... and issues the operand DMA of its next tile before the epilogue of the
+ *              finished one, so epilogue stores and first loads overlap the matrix pipe instead of arriving as one
+ *              chip-wide burst per round.  Same tiles, same arithmetic: bit-identical results.  Ignored for products with
+ *              <= G tiles, for the other kernels and together with VL_GX_IMG / VL_GX_COLSUM. */
 enum { VL_GX_TILE = 0, VL_GX_WS = 1, VL_GX_WS_FLOATS = 2, VL_GX_IMG = 3, VL_GX_IMG_COLS = 4, VL_GX_COLSUM = 5,
-       VL_GX_COLSUM_ROWS = 6, VL_GX_FIELDS = 8 };
+       VL_GX_COLSUM_ROWS = 6, VL_GX_PERSIST = 7, VL_GX_FIELDS = 8 };
 int vl_gemm_nt_ex(const void* a_hi, const void* a_lo, int64_t lda, const void* b_hi, const void* b_lo, int64_t ldb,
                   int64_t M, int64_t N, int64_t K, int passes, int epilogue, const float* bias, const float* resid32,
                   float* out32, int64_t ldc, void* out_hi, void* out_lo, void* aux16, int64_t ld16, int64_t* extra,
@@ -287,6 +292,8 @@ enum {
   VL_ST_DW_BUDGET = 36, /* > 0: the weight-gradient GEMMs run in the stream-K form on this many workgroups (vl_dw_grouped_streamk) */
   VL_ST_DW_SK_WS = 37,  /* its workspace (device pointer, zero-filled once) and size in bytes */
   VL_ST_DW_SK_WS_BYTES = 38,
+  VL_ST_GEMM_PERSIST = 39, /* VL_GX_PERSIST of the stack's GEMMs: low 16 bits for the 3-pass products of forward, next 16 for the
+                              single-pass products of backward (0 = one workgroup per tile) */
   VL_ST_FIELDS = 40
 };
 enum {

@@ -220,6 +220,39 @@ def test_gemm_epilogues(M, N, K):
     torch.testing.assert_close(dh.float(), (acc * u16.double()).float(), rtol=2 ** -7, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,N,K,persist", [(2048, 1536, 768, 8), (2048, 1536, 768, 13), (3584, 3072, 256, 40), (1000, 700, 128, 3),
+                                            (14336, 768, 768, 256), (4096, 2304, 64, 16)])
+def test_persistent_gemm_is_bit_identical_to_one_tile_per_workgroup(M, N, K, persist):
+    """VL_GX_PERSIST: a workgroup walks several tiles and prefetches the next tile's operands under the epilogue of the
+    finished one -- same tiles, same arithmetic: every epilogue and tile configuration the layer stack uses must give the
+    same bits as the one-tile-per-workgroup launch (ragged edges, a single K-tile and uneven tile counts included)."""
+    x, w, bias = _rand(M, K, seed=19), _rand(N, K, seed=20, scale=0.1), _rand(N, seed=21)
+    resid = _rand(M, N, seed=22)
+    xh, xl = _split(x)
+    wh, wl = _split(w)
+    for tile in (2, 3, 5):
+        def run(p_):
+            o = {}
+            o["f32_3"] = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm_nt(xh, xl, wh, wl, M, N, K, 3, EPI_F32, bias=bias, out32=o["f32_3"], tile=tile, persist=p_)
+            o["sh"], o["sl"] = (torch.zeros(M, N, dtype=BF16, device=DEV) for _ in range(2))
+            ops.gemm_nt(xh, xl, wh, wl, M, N, K, 3, EPI_SPLIT, bias=bias, out_hi=o["sh"], out_lo=o["sl"], tile=tile, persist=p_)
+            o["u16"], o["hh"], o["hl"] = (torch.zeros(M, N, dtype=BF16, device=DEV) for _ in range(3))
+            ops.gemm_nt(xh, xl, wh, wl, M, N, K, 3, EPI_GELU_SPLIT, bias=bias, out_hi=o["hh"], out_lo=o["hl"], aux16=o["u16"],
+                        tile=tile, persist=p_)
+            o["f32_1"] = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm_nt(xh, None, wh, None, M, N, K, 1, EPI_F32, resid=resid, out32=o["f32_1"], tile=tile, persist=p_)
+            o["bh"] = torch.zeros(M, N, dtype=BF16, device=DEV)
+            ops.gemm_nt(xh, None, wh, None, M, N, K, 1, EPI_BF16, out_hi=o["bh"], tile=tile, persist=p_)
+            o["dh"] = torch.zeros(M, N, dtype=BF16, device=DEV)
+            ops.gemm_nt(xh, None, wh, None, M, N, K, 1, EPI_DGELU_BF16, out_hi=o["dh"], aux16=o["u16"], tile=tile, persist=p_)
+            return o
+        ref, per = run(0), run(persist)
+        for k in ref:
+            assert torch.equal(ref[k].view(torch.int16) if ref[k].dtype == BF16 else ref[k], per[k].view(torch.int16) if per[k].dtype == BF16 else per[k]), (tile, k)
+    torch.testing.assert_close(ref["f32_3"].double(), x.double() @ w.double().t() + bias.double(), rtol=1e-4, atol=1e-4)
+
+
 def test_gemm_rejects_bad_arguments():
     a = torch.zeros(16, 12, dtype=BF16, device=DEV)
     out = torch.zeros(16, 16, device=DEV)
@@ -789,6 +822,70 @@ def test_gqa_loss_kernel_matches_the_reference_arithmetic(B, C):
     assert abs(out[0].item() - ref.item()) <= 2e-6 * abs(ref.item()), (out[0].item(), ref.item())
     assert out[1].item() == ref_score.item()
     torch.testing.assert_close(dl.double(), z.grad, rtol=2e-5, atol=2e-5 * z.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("K,budget", [(1024, 5), (1024, 40), (2048, 16), (14336, 88), (14336, 96), (14336, 250), (448, 9)])
+def test_dw_streamk_form_equals_the_tile_per_workgroup_form(K, budget):
+    """vl_dw_grouped_streamk (a fixed workgroup budget; tiles cut by a share boundary are completed from partial tiles):
+    against fp64; equal to one workgroup per tile up to fp32 re-association; bit-reproducible; the same bits from row-major
+    and K-major operands (same segments, same order); SFT mask, accumulation and the bias column sums ride along; the
+    hand-off flags are zero again after every launch."""
+    H, I = 768, 3072
+    dqkv, dt1, du, dt2 = (_rand(K, n, seed=160 + i, scale=0.5).to(BF16) for i, n in enumerate((3 * H, H, I, H)))
+    x, ctx, x1, hh = (_rand(K, n, seed=170 + i).to(BF16) for i, n in enumerate((H, H, H, I)))
+    mask = (torch.rand(I, H, generator=torch.Generator().manual_seed(19)) < 0.6).float().to(DEV)
+    names = ("q", "k", "v", "o", "w1", "w2")
+    shapes = dict(q=(H, H), k=(H, H), v=(H, H), o=(H, H), w1=(I, H), w2=(H, I))
+
+    def fresh():
+        outs = {n: torch.full(shapes[n], float("nan"), device=DEV) for n in names}
+        cs = {n: torch.full(((shapes[n][1] + 255) // 256, shapes[n][0]), float("nan"), device=DEV) for n in ("q", "k", "v", "w1")}
+        probs = [(dqkv[:, :H], None, x, None, outs["q"], None, H, H, cs["q"]), (dqkv[:, H:2 * H], None, x, None, outs["k"], None, H, H, cs["k"]),
+                 (dqkv[:, 2 * H:], None, x, None, outs["v"], None, H, H, cs["v"]), (dt1, None, ctx, None, outs["o"], None, H, H, None),
+                 (du, None, x1, None, outs["w1"], mask, I, H, cs["w1"]), (dt2, None, hh, None, outs["w2"], None, H, I, None)]
+        return outs, cs, probs
+    ws = ops.dw_streamk_ws(budget, DEV)
+    flags = ws[:4096].view(torch.int32)
+    o_sk, c_sk, p_sk = fresh()
+    ops.dw_grouped_mixed(p_sk, K, 3, budget=budget, ws=ws)
+    torch.cuda.synchronize()
+    assert int(flags.abs().sum()) == 0
+    o_t, c_t, p_t = fresh()
+    ops.dw_grouped_mixed(p_t, K, 3)
+    refs = dict(q=dqkv[:, :H].double().t() @ x.double(), k=dqkv[:, H:2 * H].double().t() @ x.double(),
+                v=dqkv[:, 2 * H:].double().t() @ x.double(), o=dt1.double().t() @ ctx.double(),
+                w1=(du.double().t() @ x1.double()) * mask.double(), w2=dt2.double().t() @ hh.double())
+    tol = 3e-4 * math.sqrt(max(K, 256) / 256)
+    for n in names:
+        torch.testing.assert_close(o_sk[n].double(), refs[n], rtol=2e-5, atol=tol, msg=lambda m, n=n: "%s: %s" % (n, m))
+        # fp32 re-association only: a handful of ulps of the largest partial sum
+        torch.testing.assert_close(o_sk[n], o_t[n], rtol=0, atol=4e-6 * float(refs[n].abs().max()) + 1e-6)
+    for n in c_sk:
+        torch.testing.assert_close(c_sk[n].sum(0), c_t[n].sum(0), rtol=0, atol=2e-5 * math.sqrt(K / 64) * 8)
+    # bit-reproducible, and the same bits from the K-major images (identical segments and summation order)
+    o2, c2, p2 = fresh()
+    ops.dw_grouped_mixed(p2, K, 3, budget=budget, ws=ws)
+    for n in names:
+        assert torch.equal(o_sk[n], o2[n]), n
+    for n in c_sk:
+        assert torch.equal(c_sk[n], c2[n]), n
+    mats = [dqkv, dt1, du, dt2, x, ctx, x1, hh]
+    imgs = [torch.empty(ops._lib.lib().vl_blocked_elems(K, m.shape[1]), dtype=BF16, device=DEV) for m in mats]
+    ops.transpose_blocked([(m, d, None) for m, d in zip(mats, imgs)], K)
+    Tqkv, Tt1, Tu, Tt2, Tx, Tctx, Tx1, Th = imgs
+    o3, c3, _ = fresh()
+    pk = [(Tqkv, 3 * H, Tx, H, o3["q"], None, H, H, c3["q"]), (Tqkv[64 * H:], 3 * H, Tx, H, o3["k"], None, H, H, c3["k"]),
+          (Tqkv[2 * 64 * H:], 3 * H, Tx, H, o3["v"], None, H, H, c3["v"]), (Tt1, H, Tctx, H, o3["o"], None, H, H, None),
+          (Tu, I, Tx1, H, o3["w1"], mask, I, H, c3["w1"]), (Tt2, H, Th, I, o3["w2"], None, H, I, None)]
+    ops.dw_grouped_mixed(pk, K, 0, budget=budget, ws=ws)
+    for n in names:
+        assert torch.equal(o_sk[n], o3[n]), n
+    # accumulation
+    ops.dw_grouped_mixed(p_sk, K, 3, accumulate=True, budget=budget, ws=ws)
+    for n in names:
+        assert torch.equal(o_sk[n], o2[n] + o2[n]), n
+    torch.cuda.synchronize()
+    assert int(flags.abs().sum()) == 0
 
 
 def test_gqa_loss_with_non_finite_logits_yields_nan_without_leaving_the_row():

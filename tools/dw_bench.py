@@ -49,6 +49,23 @@ def main():
         ts.sort()
         flop = 2.0 * K * (4 * H * H + 2 * H * I)
         print("mode %d: %.1f us  (%.0f TFLOP/s on %d tiles)" % (mode, ts[len(ts) // 2], flop / ts[len(ts) // 2] / 1e6, 108), flush=True)
+    # stream-K form (row-major operands) on a fixed workgroup budget
+    rm9 = [(a, None, b, None, o, m, M_, N_, c) for (a, _, b, _, o, m, M_, N_, c) in rm]
+    for budget in [int(b) for b in os.environ.get("BUDGETS", "64,72,80,88,96,108,128,160,216,256").split(",")]:
+        ws = ops.dw_streamk_ws(budget, DEV)
+        ts = []
+        for it in range(8):
+            filler.zero_()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ops.dw_grouped_mixed(rm9, K, 3, budget=budget, ws=ws)
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.sort()
+        t = ts[len(ts) // 2]
+        print("stream-K, %3d workgroups: %.1f us  (%.0f TFLOP/s = %.2f TFLOP/s per CU; %.2f us per K-tile and CU)" % (
+            budget, t, flop / t / 1e6, flop / t / 1e6 / budget, t / (108 * 224 / budget)), flush=True)
 
 
 
