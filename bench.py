@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one full training step of BASELINE.json configs[1] on one synthetic batch already resident in HBM:
+One "step" = one full training step of BASELINE.json configs[1] on a synthetic batch already resident in HBM (8 batches with
+different token ids / features are kept resident and rotated):
 forward (dropout on) + GQA loss with semantic prior + backward + gradient all-reduce (N > 1) + clip + AdamW +
 zero-grad.  Weak scaling: 256 samples per GPU.  Rank 0 prints ONE JSON line.  `--workload c3|c4|c5` runs the other
 BASELINE configs through the same code (their lines are committed under profiles/, they are not the headline).
@@ -131,12 +132,24 @@ def cpu_baseline(seconds_budget=40.0):
     from oracle import uc2_oracle as O
     from clg_vqa_amd.config import GQA_TASK_CFG, BertConfig, uc2_base_config
     from clg_vqa_amd.synthetic import make_batch
-    cores = os.cpu_count() or 1
+    # threads = the cores this process may really use: its affinity mask, cut to the cgroup's CPU quota when there is one (a
+    # one-GPU box owns a share of the host; threads beyond the quota are throttled, not run)
+    logical = os.cpu_count() or 1
+    affinity = logical
     try:
-        cores = len(os.sched_getaffinity(0))
+        affinity = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 16)  # a one-GPU box owns a 16-core share of the host; more threads only oversubscribe it
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per) + 0.5))
+    except Exception:
+        pass
+    cores = min(affinity, quota) if quota else affinity
+    if os.environ.get("BENCH_CPU_THREADS"):
+        cores = int(os.environ["BENCH_CPU_THREADS"])
     torch.set_num_threads(cores)
     print("[bench] cpu_baseline: building the oracle (UC2 full config) on %d host threads" % cores, file=sys.stderr, flush=True)
     config = BertConfig.from_dict(uc2_base_config())
@@ -173,6 +186,7 @@ def cpu_baseline(seconds_budget=40.0):
     fb, n_fb = run(False, 2, 5)
     full, n_full = run(True, 1, 5)  # (the model is warm; one more warm-up for the optimizer state allocation)
     return dict(value=mb / full, unit="samples/s", cores=cores, kind="port", cpu=cpu_model_string(),
+                host_logical_cpus=logical, affinity_cpus=affinity, cgroup_cpu_quota=quota,
                 fwd_bwd_samples_per_s=mb / fb,
                 sample="oracle (CPU restatement of volta BertForVLTasks, fp32 eager torch) UC2 full config, micro-batch 32, "
                        "T=20 V=36, dropout on: value = full step (fwd+loss+bwd+clip+AdamW+schedule, median of %d steps after "
@@ -259,6 +273,9 @@ def main():
         model.engine.stack.dw_budget = int(os.environ["BENCH_DW_BUDGET"])
     if os.environ.get("BENCH_GEMM_PERSIST"):  # A/B: persistent ping-pong GEMM, "fwd,bwd" workgroup counts (0 = tile per workgroup)
         model.engine.stack.gemm_persist = tuple(int(x) for x in os.environ["BENCH_GEMM_PERSIST"].split(","))
+    if os.environ.get("BENCH_NONDET_EMBED", "0") == "1":  # A/B: float atomics in the embedding backward (arrival order)
+        from clg_vqa_amd import ops as _ops2
+        _ops2.DETERMINISTIC_EMBED_BWD = False
     if os.environ.get("BENCH_FUSE_IMAGES"):  # A/B: K-major images by GEMM epilogues (bit 0: h, bit 1: du); 0 = re-layout
         model.engine.stack.fuse_images = int(os.environ["BENCH_FUSE_IMAGES"])
     if os.environ.get("BENCH_TR_BWD_LAYERS"):  # A/B: K-major X images of the bottom n layers written in backward
@@ -282,8 +299,14 @@ def main():
                      max_grad_norm=1.0, warmup_steps=100, t_total=100000,
                      overlap_reduce=False if os.environ.get("BENCH_LAYER_HOOK", "1") == "0" else None)
     opt.flag_sumsq = os.environ.get("BENCH_FLAG_SUMSQ", "1") != "0"
-    batch = tuple(t.to(dev) for t in make_batch(args.batch, num_boxes=num_boxes, num_locs=num_locs, l2_normalize=l2n,
-                                                seed=1234 + rank))
+    # NBATCH synthetic batches resident in HBM, rotated through the loop: every step sees other token ids (another set of
+    # touched word-embedding rows for the sparse optimizer path) and other features (no step re-reads what the last one left
+    # in the Infinity Cache)
+    nbatch = max(1, int(os.environ.get("BENCH_NBATCH", "8")))
+    batches = [tuple(t.to(dev) for t in make_batch(args.batch, num_boxes=num_boxes, num_locs=num_locs, l2_normalize=l2n,
+                                                   seed=1234 + rank + 1000 * i)) for i in range(nbatch)]
+    batch = batches[0]
+    step_no = [0]
     crit = torch.nn.CrossEntropyLoss()
     timer = GemmTimer(model.engine.stack) if os.environ.get("BENCH_NO_GEMM_TIMER", "0") != "1" else None
 
@@ -291,7 +314,9 @@ def main():
 
     def step():
         c0 = time.perf_counter()
-        loss, score = task_utils.ForwardModelsTrain(config, TASK_CFG, dev, "TASK15", batch, model, crit)
+        b_ = batches[step_no[0] % nbatch]
+        step_no[0] += 1
+        loss, score = task_utils.ForwardModelsTrain(config, TASK_CFG, dev, "TASK15", b_, model, crit)
         c1 = time.perf_counter()
         loss.backward()
         c2 = time.perf_counter()
@@ -313,6 +338,7 @@ def main():
     torch.cuda.synchronize()
     if timer is not None:
         timer.start()
+    opt.observe_exchange(world > 1)
     host[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -329,6 +355,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.detach())
+    # multi-GPU observability (read after the timed region): backend, world size, how long the main stream waited for the
+    # gradient exchange per step (HIP events around the wait loop of FusedAdamW.step) and the bytes each rank exchanged
+    dist_obs = None
+    if world > 1:
+        st = opt.exchange_stats()
+        dist_obs = dict(backend=dist.get_backend(), world_size=dist.get_world_size(), ranks_per_node=world,
+                        collective_wait_ms_per_step=st["wait_ms_per_step"], allreduce_bytes_per_step=st["dense_bytes_per_step"],
+                        sparse_allgather_bytes_per_step=st["sparse_bytes_per_step"], collectives_per_step=st["collectives_per_step"])
 
     # extras outside the contract's timed region: (i) forward+backward only, (ii) for N > 1 the reference's
     # batch semantics (task_utils.py:478-479 divides the YAML batch over the ranks: global 256, strong scaling)
@@ -430,10 +464,10 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "%s full config (12 layers, H768, 12 heads, I3072, vocab 250002), GQA 1842 labels, "
                                    "T=20 + V=%d (S=%d), bs %d per GPU, %s fine-tune with_prior, dropout 0.1, "
-                                   "full step = fwd+loss+bwd+allreduce+clip+AdamW+zero_grad" % (
+                                   "full step = fwd+loss+bwd+allreduce+clip+AdamW+zero_grad; %d resident batches rotated" % (
                                        "M3P" if args.workload == "c4" else "UC2", num_boxes, seq, args.batch,
                                        "SFT-masked (73 masks, %d elements, fp32 {0,1} layout of the reference)" % masked_elems
-                                       if args.sft else "dense"),
+                                       if args.sft else "dense", nbatch),
                        "baseline_config": args.workload, "global_batch": world * args.batch, "seq_len": seq, "parallelism": "dp%d" % world,
                        "precision": "forward GEMMs + attention 3-pass split bf16 MFMA (fp32-grade, logits within 1e-3); "
                                     "backward GEMMs + attention bf16 MFMA; fp32 residual stream / LN / optimizer",
@@ -442,11 +476,22 @@ def main():
                        "final_loss": final_loss},
             "roofline": roof,
         }
+        # step_tflops: SURVEY 8(d)'s ALGORITHMIC work / time; executed_step_tflops: what the engine really runs (the pooled-row
+        # mode of the last layer skips 55 of its 56 rows after the K/V projection) / time
         line["step_tflops"] = round(GFLOP_PER_SAMPLE[args.workload] * 1e-3 * world * args.batch / (elapsed / args.steps), 2)
+        line["executed_step_tflops"] = round(executed_gflop_per_sample(args.workload, model, seq) * 1e-3 * world * args.batch /
+                                             (elapsed / args.steps), 2)
         line["extras"] = {"fwd_bwd_only_samples_per_s": None if fb_rate is None else round(fb_rate, 1),
                           "h2d_inclusive_samples_per_s": None if h2d_rate is None else round(h2d_rate, 1),
                           "reference_semantics_global256_samples_per_s": None if strong_rate is None else round(strong_rate, 1),
-                          "host_enqueue_ms_per_step": round(1e3 * sum(host) / args.steps, 2)}
+                          "host_enqueue_ms_per_step": round(1e3 * sum(host) / args.steps, 2),
+                          "host_enqueue_ms_by_phase": {"forward": round(1e3 * host[0] / args.steps, 2),
+                                                       "backward": round(1e3 * host[1] / args.steps, 2),
+                                                       "optimizer": round(1e3 * host[2] / args.steps, 2)},
+                          "resident_batches_rotated": nbatch,
+                          "adamw_touched_word_rows_per_step": "<= %d (sparse optimizer path: only rows that ever received a "
+                                                              "gradient carry state)" % (args.batch * 20)}
+        line["dist"] = dist_obs
         print("[bench] gpu part done: %.1f samples/s, %.2f ms/step" % (value, 1e3 * elapsed / args.steps), file=sys.stderr, flush=True)
         if world == 1 and not args.no_cpu_baseline:
             del model, opt

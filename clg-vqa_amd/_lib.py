@@ -71,11 +71,15 @@ _SIGS = {
     "vl_embed_gather_fwd": (c_int, [P, P, P, c_int64, c_int64, P]),
     "vl_embed_scatter_add": (c_int, [P, P, P, c_int64, c_int64, c_int64, P, P]),
     "vl_loc_linear_fwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
-    "vl_loc_linear_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P]),
+    "vl_loc_linear_bwd": (c_int, [P, P, P, P, c_int64, c_int64, c_int64, P, P]),
+    "vl_loc_bwd_ws_floats": (c_int64, [c_int64, c_int64]),
+    "vl_scatter_det_ws_bytes": (c_int64, [c_int64, c_int64, c_int64]),
+    "vl_scatter_add_det": (c_int, [P, c_int64, P, c_int64, c_int64, P, c_int64, P]),
     "vl_adamw": (c_int, [P, P, P, P, c_int64, P, P, P, c_int64, c_float, c_float, c_float, c_int64, P, c_int, c_float,
                          P, c_float, P, c_float, c_float, P, c_int, P, c_int64, c_int64, c_int64, P]),
-    "vl_sumsq": (c_int, [P, c_int64, P, P]),
-    "vl_sumsq_flagged": (c_int, [P, c_int64, P, P, c_int64, c_int64, c_int64, P]),
+    "vl_sumsq_ws_floats": (c_int64, []),
+    "vl_sumsq": (c_int, [P, c_int64, P, P, P]),
+    "vl_sumsq_flagged": (c_int, [P, c_int64, P, P, c_int64, c_int64, c_int64, P, P]),
 }
 
 

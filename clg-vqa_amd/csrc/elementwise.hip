@@ -359,8 +359,10 @@ __global__ __launch_bounds__(256) void loc_fwd_kernel(const float* __restrict__ 
 // dW[c][l] += sum_r dy[r][c] loc[r][l], db[c] += sum_r dy[r][c].  Workgroup = 64 rows x 64 columns: thread (tx = column, ty =
 // one of 4 row groups) walks 16 rows, the 4 groups are combined in LDS and 64 threads issue the atomics -- 12 x more
 // workgroups and 4 x shorter dependent chains than one workgroup per 64 full rows (145 us at c2), the same number of atomics.
+// ws != NULL: the deterministic form -- every workgroup stores its partial sums to ws[row block][l][c] (l = 8: the bias) and
+// loc_bwd_reduce_kernel adds the row blocks in order; ws == NULL: float atomics straight into dw / db.
 __global__ __launch_bounds__(256) void loc_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ dy,
-                                                      float* dw, float* db, long R, int L, int H) {
+                                                      float* dw, float* db, long R, int L, int H, float* ws) {
   __shared__ float red[4][9][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int cblocks = (H + 63) / 64;
@@ -386,11 +388,36 @@ __global__ __launch_bounds__(256) void loc_bwd_kernel(const float* __restrict__ 
   red[ty][8][tx] = accb;
   __syncthreads();
   if (ty == 0 && c < H) {
+    if (ws) {
+      float* dst = ws + rb * 9 * (long)H + c;
+      dst[8 * (long)H] = (red[0][8][tx] + red[1][8][tx]) + (red[2][8][tx] + red[3][8][tx]);
+#pragma unroll
+      for (int l = 0; l < 8; ++l)
+        if (l < L) dst[l * (long)H] = (red[0][l][tx] + red[1][l][tx]) + (red[2][l][tx] + red[3][l][tx]);
+      return;
+    }
     atomicAdd(db + c, (red[0][8][tx] + red[1][8][tx]) + (red[2][8][tx] + red[3][8][tx]));
 #pragma unroll
     for (int l = 0; l < 8; ++l)
       if (l < L) atomicAdd(dw + c * L + l, (red[0][l][tx] + red[1][l][tx]) + (red[2][l][tx] + red[3][l][tx]));
   }
+}
+// dw[c][l] += sum over the row blocks (fixed order, two independent chains), db likewise from slot l = 8
+__global__ __launch_bounds__(256) void loc_bwd_reduce_kernel(const float* __restrict__ ws, float* dw, float* db, int nrb, int L,
+                                                             int H) {
+  const int c = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;  // l in [0, L] (L = the bias slot 8)
+  if (c >= H) return;
+  const int slot = l < L ? l : 8;
+  const float* src = ws + slot * (long)H + c;
+  float s0 = 0.f, s1 = 0.f;
+  int b = 0;
+  for (; b + 1 < nrb; b += 2) {
+    s0 += src[(long)b * 9 * H];
+    s1 += src[(long)(b + 1) * 9 * H];
+  }
+  if (b < nrb) s0 += src[(long)b * 9 * H];
+  if (l < L) dw[c * L + l] += s0 + s1;
+  else db[c] += s0 + s1;
 }
 
 // ---- fused AdamW over a flat arena ---------------------------------------------------------------------------
@@ -503,9 +530,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, float
 
 // out += sum(x^2).  Optional flagged range (the word-embedding gradient inside the flat arena): rows whose flag is 0
 // never received a gradient, their gradient is exactly zero and they are not read (0.77 GB of zeros per step at c2).
+// part != NULL: the deterministic form -- block b stores its sum to part[b] and sumsq_finish_kernel adds the blocks in order.
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* out,
                                                     const unsigned char* __restrict__ row_flags, long fl_beg4,
-                                                    long fl_end4, int fl_row4) {
+                                                    long fl_end4, int fl_row4, float* part) {
   __shared__ float red[4];
   float s = 0.f;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -535,7 +563,20 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+  if (threadIdx.x == 0) {
+    const float t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (part) part[blockIdx.x] = t;
+    else atomicAdd(out, t);
+  }
+}
+__global__ __launch_bounds__(256) void sumsq_finish_kernel(const float* __restrict__ part, int nblocks, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nblocks; i += 256) s += part[i];  // fixed assignment, fixed order
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 }  // namespace
@@ -671,11 +712,16 @@ extern "C" int vl_loc_linear_fwd(const float* loc, const float* w, const float* 
   VL_CHECK_LAUNCH("vl_loc_linear_fwd");
   return 0;
 }
+extern "C" int64_t vl_loc_bwd_ws_floats(int64_t R, int64_t H) { return R > 0 && H > 0 ? ((R + 63) / 64) * 9 * H : 0; }
 extern "C" int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db, int64_t R, int64_t L,
-                                 int64_t H, void* stream) {
+                                 int64_t H, float* ws, void* stream) {
   VL_CHECK_ARG(loc && dy32 && dw && db && R > 0 && L > 0 && L <= 8 && H > 0, "vl_loc_linear_bwd: bad arguments (L <= 8)");
-  hipLaunchKernelGGL(loc_bwd_kernel, dim3((unsigned)(((R + 63) / 64) * ((H + 63) / 64))), dim3(256), 0, (hipStream_t)stream, loc, dy32, dw,
-                     db, (long)R, (int)L, (int)H);
+  const int64_t nrb = (R + 63) / 64;
+  hipLaunchKernelGGL(loc_bwd_kernel, dim3((unsigned)(nrb * ((H + 63) / 64))), dim3(256), 0, (hipStream_t)stream, loc, dy32, dw,
+                     db, (long)R, (int)L, (int)H, ws);
+  if (ws)
+    hipLaunchKernelGGL(loc_bwd_reduce_kernel, dim3((unsigned)((H + 255) / 256), (unsigned)(L + 1)), dim3(256), 0, (hipStream_t)stream,
+                       ws, dw, db, (int)nrb, (int)L, (int)H);
   VL_CHECK_LAUNCH("vl_loc_linear_bwd");
   return 0;
 }
@@ -705,23 +751,28 @@ extern "C" int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_av
   return 0;
 }
 
-extern "C" int vl_sumsq(const float* x, int64_t n, float* out, void* stream) {
-  VL_CHECK_ARG(x && out && n > 0 && ((uintptr_t)x & 15) == 0, "vl_sumsq: bad arguments (x must be 16-byte aligned)");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out,
-                     (const unsigned char*)nullptr, 0L, 0L, 1);
-  VL_CHECK_LAUNCH("vl_sumsq");
+extern "C" int64_t vl_sumsq_ws_floats(void) { return 2048; }
+static int sumsq_launch(const char* fn, const float* x, int64_t n, float* out, const uint8_t* row_flags, int64_t flag_begin,
+                        int64_t flag_rows, int64_t flag_row_len, float* ws, void* stream) {
+  VL_CHECK_ARG(!ws || ((uintptr_t)ws & 3) == 0, "%s: bad workspace", fn);
+  const unsigned grid = grid_for(n / 4 + 1, 256, 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (long)n, out, (const unsigned char*)row_flags,
+                     (long)(flag_begin / 4), (long)((flag_begin + flag_rows * flag_row_len) / 4),
+                     (int)(row_flags ? flag_row_len / 4 : 1), ws);
+  if (ws) hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ws, (int)grid, out);
+  VL_CHECK_LAUNCH(fn);
   return 0;
+}
+extern "C" int vl_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream) {
+  VL_CHECK_ARG(x && out && n > 0 && ((uintptr_t)x & 15) == 0, "vl_sumsq: bad arguments (x must be 16-byte aligned)");
+  return sumsq_launch("vl_sumsq", x, n, out, nullptr, 0, 0, 1, ws, stream);
 }
 // ... skipping the rows of [flag_begin, flag_begin + flag_rows * flag_row_len) whose flag is 0 (same flagged-table
 // arguments as vl_adamw: rows that never received a gradient hold exact zeros)
 extern "C" int vl_sumsq_flagged(const float* x, int64_t n, float* out, const uint8_t* row_flags, int64_t flag_begin,
-                                int64_t flag_rows, int64_t flag_row_len, void* stream) {
+                                int64_t flag_rows, int64_t flag_row_len, float* ws, void* stream) {
   VL_CHECK_ARG(x && out && n > 0 && ((uintptr_t)x & 15) == 0 && row_flags, "vl_sumsq_flagged: bad arguments");
   VL_CHECK_ARG(flag_begin % 4 == 0 && flag_row_len % 4 == 0 && flag_row_len > 0 && flag_rows > 0 &&
                flag_begin + flag_rows * flag_row_len <= n, "vl_sumsq_flagged: flagged range must be 4-aligned and inside x");
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream, x, (long)n, out,
-                     row_flags, (long)(flag_begin / 4), (long)((flag_begin + flag_rows * flag_row_len) / 4),
-                     (int)(flag_row_len / 4));
-  VL_CHECK_LAUNCH("vl_sumsq_flagged");
-  return 0;
+  return sumsq_launch("vl_sumsq_flagged", x, n, out, row_flags, flag_begin, flag_rows, flag_row_len, ws, stream);
 }

@@ -123,6 +123,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
 #ifndef VL_LN_BWD_MINWG
 #define VL_LN_BWD_MINWG 1  // (A/B builds: workgroups per CU the register allocation must allow)
 #endif
+#ifndef VL_LN_BWD_RPT
+#define VL_LN_BWD_RPT 4    // rows per trip and wave (loads of all of them are issued before the first is reduced)
+#endif
 template <int NV>
 __global__ __launch_bounds__(256, VL_LN_BWD_MINWG) void ln_bwd_kernel(LnArgs p) {
   __shared__ float red[3][4][NV * 256];
@@ -131,14 +134,24 @@ __global__ __launch_bounds__(256, VL_LN_BWD_MINWG) void ln_bwd_kernel(LnArgs p) 
   float4 ag[NV], ab[NV], ap[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) ag[i] = ab[i] = ap[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const long half = (long)gridDim.x * 4;
-  for (long r0 = (long)blockIdx.x * 4 + wave; r0 < p.M; r0 += 2 * half) {
-    float4 dy[2][NV], zz[2][NV];
-    long rr[2] = {r0, r0 + half};
-    bool ok[2] = {true, r0 + half < p.M};
-    long orow[2];
+  constexpr int RPT = VL_LN_BWD_RPT;
+  float4 gam[NV];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    gam[i] = c < p.H ? *reinterpret_cast<const float4*>(p.gamma + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const long half = (long)gridDim.x * 4;  // rows one pass of the grid covers
+  for (long r0 = (long)blockIdx.x * 4 + wave; r0 < p.M; r0 += RPT * half) {
+    float4 dy[RPT][NV], zz[RPT][NV];
+    long rr[RPT];
+    bool ok[RPT];
+    long orow[RPT];
+    float mus[RPT], rss[RPT], rqs[RPT], rps[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+      rr[k] = r0 + k * half;
+      ok[k] = rr[k] < p.M;
       if (!ok[k]) rr[k] = r0;  // (loads a valid row; its results are discarded)
       // original (un-compacted) row index: the dropout RNG and the row masks are indexed by it
       orow[k] = map_row(p, rr[k]);
@@ -149,12 +162,18 @@ __global__ __launch_bounds__(256, VL_LN_BWD_MINWG) void ln_bwd_kernel(LnArgs p) 
         dy[k][i] = *reinterpret_cast<const float4*>(p.dy + orow[k] * p.H + c);
         zz[k][i] = *reinterpret_cast<const float4*>(p.z + rr[k] * p.H + c);
       }
+      // (the row statistics ride with the row loads: fetched inside the per-row section below, each would expose a full
+      // memory latency per row)
+      mus[k] = p.mean[rr[k]];
+      rss[k] = p.rstd[rr[k]];
+      rqs[k] = p.row_post ? p.row_post[rr[k] * p.orig_stride] : 1.f;
+      rps[k] = p.row_pre ? p.row_pre[rr[k] * p.orig_stride] : 1.f;
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < RPT; ++k) {
       if (!ok[k]) continue;
       const long r = rr[k];
-      const float mu = p.mean[r], rs = p.rstd[r];
+      const float mu = mus[k], rs = rss[k];
       float4 xh[NV];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -169,11 +188,11 @@ __global__ __launch_bounds__(256, VL_LN_BWD_MINWG) void ln_bwd_kernel(LnArgs p) 
           d.x *= ks_[0]; d.y *= ks_[1]; d.z *= ks_[2]; d.w *= ks_[3];
         }
         if (p.row_post) {
-          const float rq = p.row_post[r * p.orig_stride];
+          const float rq = rqs[k];
           d.x *= rq; d.y *= rq; d.z *= rq; d.w *= rq;
         }
         const float4 z = zz[k][i];
-        const float4 g = *reinterpret_cast<const float4*>(p.gamma + c);
+        const float4 g = gam[i];
         float4 x;
         x.x = (z.x - mu) * rs; x.y = (z.y - mu) * rs; x.z = (z.z - mu) * rs; x.w = (z.w - mu) * rs;
         ag[i].x += d.x * x.x; ag[i].y += d.y * x.y; ag[i].z += d.z * x.z; ag[i].w += d.w * x.w;
@@ -195,7 +214,7 @@ __global__ __launch_bounds__(256, VL_LN_BWD_MINWG) void ln_bwd_kernel(LnArgs p) 
         dz.z = (dy[k][i].z - c1 - xh[i].z * c2) * rs;
         dz.w = (dy[k][i].w - c1 - xh[i].w * c2) * rs;
         if (p.row_pre) {
-          const float rp = p.row_pre[r * p.orig_stride];
+          const float rp = rps[k];
           dz.x *= rp; dz.y *= rp; dz.z *= rp; dz.w *= rp;
         }
         if (p.dz) *reinterpret_cast<float4*>(p.dz + e) = dz;
@@ -256,8 +275,10 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(LnReduceArgs a) {
 }
 
 #ifndef VL_LN_BWD_BLOCKS
-#define VL_LN_BWD_BLOCKS 384  // measured beside the row-major dW GEMM (108 CUs busy on the side stream), ms / step, same box:
-                              // 192: 16.76, 256: 16.62, 320: 16.64, 384: 16.55, 512: 16.78, 768: 16.63, 1024 / 2048: worse (partials)
+#define VL_LN_BWD_BLOCKS 512  // round 2 (2 rows per trip, row statistics fetched per row), ms / step beside the dW GEMM, same box:
+                              // 192: 16.76, 256: 16.62, 320: 16.64, 384: 16.55, 512: 16.78, 768: 16.63, 1024 / 2048: worse (partials);
+                              // round 3 (4 rows per trip, statistics / gamma hoisted; profiles/r03_ab_log.txt): kernel alone warm /
+                              // cold 384: 39.6 / 53.2 us, 512: 36.8 / 51.6; step 384: 16.73 / 16.74, 512: 16.68
 #endif
 constexpr int LN_BWD_BLOCKS = VL_LN_BWD_BLOCKS;
 int nblk_for(int64_t M) {

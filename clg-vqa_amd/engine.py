@@ -9,10 +9,13 @@ Reference call stack restated here: BertModel.forward (volta/v
 UC2Embeddings.forward (volta/volta/embeddings.py:636-669) -> BertEncoder.forward (encoders.py:848-892) ->
 24 x {BertGatedAttention :434 | BertGatedFeedForward :576}, in the single-stream form of SURVEY.md Appendix A.
 
-Data layout in HBM (B = batch, T text tokens, V boxes, S = T + V, M = B*S rows, H hidden, I intermediate):
+Data layout in HBM (B = batch, T text tokens, V boxes, S = T + V, M = B*S rows, H hidden, I intermediate; DESIGN.md section 3):
   stream  x32 [M,H] fp32 (residual stream) + (x_hi, x_lo) bf16 split feeding the 3-pass forward GEMMs
-  qkv32   [M,3H] fp32, columns [Q|K|V]             ctx (hi,lo) [M,H] bf16
-  u16/h   [M,I] bf16 pre-activation / GELU output  weights: (hi,lo) [N,K] + transposed hi [K,N], rebuilt per step
+  qkv     (hi, lo) [M,3H] bf16 x 2, columns [Q|K|V], written by the projection's epilogue and read in place by attention
+          (no fp32 copy);  ctx (hi, lo) [M,H] bf16
+  u16     [M,I] bf16 = GELU'(pre-activation) for the backward epilogue;  h (hi, lo) [M,I] bf16 = GELU output
+  weights (hi, lo) [N,K] + transposed hi [K,N], Q|K|V packed, rebuilt once per step by one launch (SFT mask folded in)
+All of it lives in a StackArena allocated once per batch shape; the 12-layer stack is ONE native call per direction.
 """
 import weakref
 
@@ -806,8 +809,10 @@ class UC2Engine(EngineBase):
         dz_t, dg_e, db_e = f32(BT, H), f32(H), f32(H)
         ops.ln_bwd(dy, sv["z_t"], sv["mean_t"], sv["rstd_t"], emb.LayerNorm.weight.detach(), dz_t, None, None, dg_e,
                    db_e, None, ws, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
-        ops.embed_text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id),
-                           row_flags=self.word_row_flags if use_sink else None)
+        # (fixed summation order: sort + run sums, csrc/scatter.hip; beyond 16384 text rows the atomic kernel)
+        text_bwd = ops.embed_text_bwd_det if ops.DETERMINISTIC_EMBED_BWD and BT <= 16384 else ops.embed_text_bwd
+        text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id),
+                 row_flags=self.word_row_flags if use_sink else None)
         if defer:
             self._push_word_grad(sv["ids"].view(-1), dz_t, int(cfg.pad_token_id))
         dtype_[1] += dtype1  # image_token_type_embeddings is new_token_type_embeddings (embeddings.py:628)

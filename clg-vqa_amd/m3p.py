@@ -242,8 +242,12 @@ class M3PEngine(EngineBase):
         if defer:
             self._push_word_grad(sv["ids"].view(-1), dz_t, int(c.pad_index))
         else:
-            ops.embed_scatter_add(sv["ids"], dz_t, dword, BT, H, int(c.pad_index),
-                                  row_flags=self.word_row_flags if use_sink else None)
+            if ops.DETERMINISTIC_EMBED_BWD and BT <= 16384:  # fixed summation order (csrc/scatter.hip)
+                ops.scatter_add_det([(sv["ids"].view(-1), 0, dword, int(c.pad_index),
+                                      self.word_row_flags if use_sink else None, T)], dz_t, BT, H)
+            else:
+                ops.embed_scatter_add(sv["ids"], dz_t, dword, BT, H, int(c.pad_index),
+                                      row_flags=self.word_row_flags if use_sink else None)
         dpos[V:V + T] += dz_t.view(B, T, H).sum(0)
         # image rows
         dz2, dg_2, db_2 = f32(BV, H), f32(H), f32(H)

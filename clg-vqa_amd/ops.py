@@ -392,9 +392,43 @@ def loc_linear_fwd(loc, w, b, y32, R, L, H):
     _lib.check(_lib.lib().vl_loc_linear_fwd(_p(loc), _p(w), _p(b), _p(y32), R, L, H, _stream()), "vl_loc_linear_fwd")
 
 
-def loc_linear_bwd(loc, dy32, dw, db, R, L, H):
-    _lib.check(_lib.lib().vl_loc_linear_bwd(_p(loc), _p(dy32), _p(dw), _p(db), R, L, H, _stream()),
+DETERMINISTIC_EMBED_BWD = True  # fixed-order reductions in the embedding backward (False: float atomics, arrival order)
+
+
+def loc_linear_bwd(loc, dy32, dw, db, R, L, H, deterministic=None):
+    """dw [H, L], db [H] += ...; deterministic: row blocks summed in a fixed order through a workspace (default), else
+    float atomics."""
+    det = DETERMINISTIC_EMBED_BWD if deterministic is None else deterministic
+    ws = _tmp(torch.empty(_lib.lib().vl_loc_bwd_ws_floats(R, H), dtype=torch.float32, device=dy32.device)) if det else None
+    _lib.check(_lib.lib().vl_loc_linear_bwd(_p(loc), _p(dy32), _p(dw), _p(db), R, L, H, _p(ws), _stream()),
                "vl_loc_linear_bwd")
+
+
+def scatter_add_det(tables, dz32, R, H):
+    """Deterministic scatter-add of the rows of dz32 [R, H] into several tables at once (csrc/scatter.hip).
+    tables = [(ids int64 [R], kind, table fp32 [rows, H], skip, row_flags or None, T)] -- see vl_scatter_add_det."""
+    import ctypes
+    n = len(tables)
+    arr = (ctypes.c_int64 * (6 * n))()
+    for i, (ids, kind, table, skip, flags, T) in enumerate(tables):
+        assert ids.is_contiguous() and ids.dtype == torch.int64 and table.is_contiguous() and table.dtype == torch.float32
+        arr[6 * i:6 * i + 6] = [_p(ids), kind, _p(table), skip, 0 if flags is None else _p(flags), T]
+    L = _lib.lib()
+    nbytes = L.vl_scatter_det_ws_bytes(n, R, H)
+    ws = _tmp(torch.empty(nbytes, dtype=torch.uint8, device=dz32.device))
+    _lib.check(L.vl_scatter_add_det(ctypes.cast(arr, ctypes.c_void_p), n, _p(dz32), R, H, _p(ws), nbytes, _stream()),
+               "vl_scatter_add_det")
+
+
+def embed_text_bwd_det(ids, seg, dz32, dword, dpos, dtyp, B, T, H, pad_id, row_flags=None):
+    """embed_text_bwd with a fixed summation order (same destinations, same semantics: the pad row of the word table receives
+    nothing, dword may be None)."""
+    tabs = []
+    if dword is not None:
+        tabs.append((ids.view(-1), 0, dword, pad_id, row_flags, T))
+    tabs.append((ids.view(-1), 1, dpos, pad_id, None, T))
+    tabs.append((seg.view(-1), 0, dtyp, -1, None, T))
+    scatter_add_det(tabs, dz32, B * T, H)
 
 
 def adamw(param, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, seg_wd, beta1, beta2, eps, step, correct_bias, lr_mult,
@@ -410,9 +444,11 @@ def adamw(param, grad, exp_avg, exp_avg_sq, seg_end, seg_lr, seg_wd, beta1, beta
                                    flag_row_len, _stream()), "vl_adamw")
 
 
-def sumsq(x, out, row_flags=None, flag_begin=0, flag_rows=0, flag_row_len=0):
+def sumsq(x, out, row_flags=None, flag_begin=0, flag_rows=0, flag_row_len=0, ws=None):
+    """out[0] += sum(x^2).  ws (fp32, >= vl_sumsq_ws_floats()): fixed-order two-launch reduction (bit-reproducible) instead
+    of float atomics."""
     if row_flags is None:
-        _lib.check(_lib.lib().vl_sumsq(_p(x), x.numel(), _p(out), _stream()), "vl_sumsq")
+        _lib.check(_lib.lib().vl_sumsq(_p(x), x.numel(), _p(out), _p(ws), _stream()), "vl_sumsq")
     else:
         _lib.check(_lib.lib().vl_sumsq_flagged(_p(x), x.numel(), _p(out), _p(row_flags), flag_begin, flag_rows,
-                                               flag_row_len, _stream()), "vl_sumsq_flagged")
+                                               flag_row_len, _p(ws), _stream()), "vl_sumsq_flagged")

@@ -193,6 +193,7 @@ class FusedAdamW(object):
         self.seg_steps = [0] * len(self.groups)
         self._seg_step_dev = None
         self._sumsq = torch.zeros(2, dtype=torch.float32, device=device)  # two accumulators alternate: AdamW zeroes the next
+        self._sumsq_ws = torch.empty(2048, dtype=torch.float32, device=device)  # fixed-order reduction of the block sums
         self.return_norm = False  # step() returns the gradient norm tensor (one extra tiny launch) only on request
         if hasattr(model, "mark_weights_dirty"):
             model.mark_weights_dirty()
@@ -249,6 +250,20 @@ class FusedAdamW(object):
             eng.stack.layer_done_hook = self._on_layer_grads
             eng.stack.grad_sink = self._sink_for_layer
 
+    def observe_exchange(self, enabled):
+        """Multi-GPU observability: bracket the wait for the gradient exchange in step() with HIP events and count the bytes
+        (read with exchange_stats(); the events cost two records per step)."""
+        self._obs = dict(pairs=[], dense=0, sparse=0, colls=0, steps=0) if enabled else None
+
+    def exchange_stats(self):
+        o = getattr(self, "_obs", None)
+        if not o or not o["steps"]:
+            return dict(wait_ms_per_step=None, dense_bytes_per_step=0, sparse_bytes_per_step=0, collectives_per_step=0)
+        torch.cuda.synchronize()
+        wait = sum(a.elapsed_time(b) for a, b in o["pairs"]) / o["steps"]
+        return dict(wait_ms_per_step=round(wait, 4), dense_bytes_per_step=o["dense"] // o["steps"],
+                    sparse_bytes_per_step=o["sparse"] // o["steps"], collectives_per_step=round(o["colls"] / o["steps"], 1))
+
     def set_overlap(self, enabled):
         """Switch the during-backward gradient exchange on / off (off: everything is reduced inside step())."""
         eng = getattr(self.model, "engine", None)
@@ -285,7 +300,12 @@ class FusedAdamW(object):
             elif dst:
                 torch._foreach_copy_(dst, src)
             if self.reducer.world_size() > 1:
-                self._works += self.reducer.allreduce_async(self.arena.grad, ranges)
+                works = self.reducer.allreduce_async(self.arena.grad, ranges)
+                self._works += works
+                o = getattr(self, "_obs", None)
+                if o is not None:
+                    o["dense"] += 4 * sum(hi - lo for lo, hi in ranges)
+                    o["colls"] += len(works)
         self._pre.update(idx)
         return True
 
@@ -387,6 +407,13 @@ class FusedAdamW(object):
                                                                      row_flags=self.row_flags))
             off = a.offsets[self._sink_index]
             skip = (off, off + (gv.numel() + 3) // 4 * 4)
+        obs = getattr(self, "_obs", None)
+        if obs is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            if skip is not None:
+                obs["sparse"] += self.reducer.world_size() * ids.numel() * (8 + 4 * H)
+                obs["colls"] += 2
         for w in self._works:  # layer exchanges launched during backward
             w.wait()
         self._works = []
@@ -408,8 +435,15 @@ class FusedAdamW(object):
             if lo is not None:
                 ranges.append((lo, hi))
             post = self.reducer.allreduce_(a.grad, ranges=ranges)
+            if obs is not None:
+                obs["dense"] += 4 * sum(hi - lo for lo, hi in ranges)
+                obs["colls"] += sum((hi - lo + self.reducer.bucket_elems - 1) // self.reducer.bucket_elems for lo, hi in ranges)
         else:
             post = 1.0
+        if obs is not None:
+            ev1.record()  # the main stream has now waited for every collective of this step
+            obs["pairs"].append((ev0, ev1))
+            obs["steps"] += 1
         self._pre = set()
         if self.keep_reduced_grad:  # tests: the summed gradient and the 1/world factor the kernels apply to it
             self.last_reduced_grad, self.last_post = a.grad.clone(), post
@@ -417,7 +451,7 @@ class FusedAdamW(object):
         # received a gradient are exact zeros: not read); the clip coefficient min(1, max_norm / (||g|| + 1e-6)) with
         # ||g|| of the averaged gradient is computed by the AdamW kernel itself -- no scalar glue kernels in between
         cur, nxt = self._sumsq[self.opt_step % 2:self.opt_step % 2 + 1], self._sumsq[(self.opt_step + 1) % 2:(self.opt_step + 1) % 2 + 1]
-        ops.sumsq(a.grad, cur, **(self._flag_args() if self.flag_sumsq else {}))
+        ops.sumsq(a.grad, cur, ws=self._sumsq_ws, **(self._flag_args() if self.flag_sumsq else {}))
         norm = (cur.sqrt() * post) if self.return_norm else None
         self.opt_step += 1
         uniform = True

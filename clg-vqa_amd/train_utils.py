@@ -8,11 +8,12 @@ import torch
 
 
 def freeze_layers(model):
-    """train_utils.py:305-311."""
-    fixed = set(getattr(model.config, "fixed_layers", []) or [])
+    """train_utils.py:305-311: every parameter whose name CONTAINS one of config.fixed_layers (e.g. "embeddings",
+    "v_embeddings.LayerNorm", "encoder.layer.3.") stops receiving gradients."""
+    fixed = [str(n) for n in (getattr(model.config, "fixed_layers", []) or [])]
     for key, value in dict(model.named_parameters()).items():
-        for i in fixed:
-            if "bert.encoder.layer.%d." % int(i) in key or ("embeddings" in key and "embeddings" in fixed):
+        for name in fixed:
+            if name in key:
                 value.requires_grad = False
 
 

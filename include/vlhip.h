@@ -438,9 +438,25 @@ int vl_embed_scatter_add(const int64_t* ids, const float* dz32, float* dtable, i
  * skip the optimizer state of embedding rows that were never touched (exactly: their update is p *= 1 - lr*wd). */
 int vl_loc_linear_fwd(const float* loc, const float* w, const float* b, float* y32, int64_t R, int64_t L, int64_t H,
                       void* stream);
-/* dw [H,L], db [H] are ACCUMULATED with atomics: zero them first. */
+/* dw [H,L], db [H] are ADDED to: zero them first.  ws (may be NULL): vl_loc_bwd_ws_floats(R, H) floats -- with it the row
+ * blocks are summed in a fixed order by a second launch (bit-reproducible); without it float atomics add them in arrival
+ * order. */
+int64_t vl_loc_bwd_ws_floats(int64_t R, int64_t H);
 int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw, float* db, int64_t R, int64_t L, int64_t H,
-                      void* stream);
+                      float* ws, void* stream);
+/* DETERMINISTIC scatter-add of gradient rows into up to 4 embedding tables that all take their rows from dz32 [R, H]
+ * (csrc/scatter.hip): the backward of nn.Embedding(sparse=False) (word / position / token-type tables of UC2Embeddings,
+ * volta/volta/embeddings.py:617-655; M3P's self.embeddings(x), m3p_transformer.py:908) with a FIXED summation order -- sort
+ * of (row id, source index) pairs, run sums in source order, one owner per table row, no atomics -- where torch's backward
+ * and vl_embed_text_bwd / vl_embed_scatter_add add in arrival order.  `tab`: HOST array of n x VL_SC_FIELDS int64 {ids
+ * (device int64 [R]), kind, table (fp32 [rows, H], ADDED to), skip, row_flags (device uint8 per table row, or 0), T}:
+ * kind 0 -- row = ids[r], rows with ids[r] == skip receive nothing (skip = -1: none); kind 1 -- row = the RoBERTa position
+ * id of token r of `ids` viewed as [R / T, T] with pad id `skip` (embeddings.py:157-170).  R <= 16384, H a multiple of 64.
+ * ws: vl_scatter_det_ws_bytes(n, R, H) bytes, 256-byte aligned, caller-owned. */
+#define VL_SC_FIELDS 6
+int64_t vl_scatter_det_ws_bytes(int64_t n, int64_t R, int64_t H);
+int vl_scatter_add_det(const int64_t* tab, int64_t n, const float* dz32, int64_t R, int64_t H, void* ws, int64_t ws_bytes,
+                       void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Element-wise stages of the pooler / classifier head on [M = batch, N] fp32 tensors (contiguous, ld = N).
@@ -500,12 +516,15 @@ int vl_adamw(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64
              const float* sumsq_dev, float max_norm, float post, float* sumsq_next,
              int zero_grad, const uint8_t* row_flags, int64_t flag_begin, int64_t flag_rows, int64_t flag_row_len,
              void* stream);
-/* out[0] += sum(x^2) over n floats (atomic; zero out[0] first). */
-int vl_sumsq(const float* x, int64_t n, float* out, void* stream);
+/* out[0] += sum(x^2) over n floats (zero out[0] first).  ws (may be NULL): vl_sumsq_ws_floats() floats -- with it the
+ * workgroups' partial sums are added in a fixed order by a second launch (bit-reproducible clip coefficient); without it
+ * they are added by float atomics in arrival order. */
+int64_t vl_sumsq_ws_floats(void);
+int vl_sumsq(const float* x, int64_t n, float* out, float* ws, void* stream);
 /* same, not reading the rows of the flagged table range (vl_adamw's row_flags arguments) whose flag is 0: they never
  * received a gradient and hold exact zeros */
 int vl_sumsq_flagged(const float* x, int64_t n, float* out, const uint8_t* row_flags, int64_t flag_begin,
-                     int64_t flag_rows, int64_t flag_row_len, void* stream);
+                     int64_t flag_rows, int64_t flag_row_len, float* ws, void* stream);
 
 #ifdef __cplusplus
 }

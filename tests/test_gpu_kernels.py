@@ -426,6 +426,70 @@ def test_addmask_embeddings_loc():
     torch.testing.assert_close(db, dy.sum(0), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,T,H,vocab", [(256, 20, 768, 250002), (37, 23, 128, 50), (2, 5, 64, 9), (64, 40, 256, 300)])
+def test_deterministic_scatter_add_matches_index_add_and_is_reproducible(B, T, H, vocab):
+    """vl_scatter_add_det (sort + ordered run sums, one owner per table row) = nn.Embedding's dense backward for the word
+    (padding_idx skipped), RoBERTa-position and token-type tables; bit-equal across runs; rows add to what is there."""
+    g = torch.Generator().manual_seed(B + T)
+    pad = 1
+    ids = torch.randint(2, min(vocab, 40), (B, T), generator=g)   # few distinct ids: long runs, many block crossings
+    ids[:, 0] = 0
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    for b in range(B):
+        ids[b, int(lens[b]):] = pad
+    if B > 2:
+        ids[1, 2] = pad  # a pad in the middle of a sample: the position ids must follow the cumulative count
+    seg = torch.randint(0, 2, (B, T), generator=g)
+    ids, seg = ids.to(DEV), seg.to(DEV)
+    R = B * T
+    dz = _rand(R, H, seed=5)
+    nz = (ids != pad).long()
+    pos_ids = (torch.cumsum(nz, 1) * nz + pad).view(-1)          # embeddings.py:157-170
+    base = [_rand(vocab if vocab < 1000 else 64, H, seed=6), _rand(T + 3, H, seed=7), _rand(2, H, seed=8)]
+    if vocab >= 1000:
+        base[0] = torch.zeros(vocab, H, device=DEV)
+    outs = []
+    for rep in range(2):
+        dword, dpos, dtyp = (t.clone() for t in base)
+        flags = torch.zeros(dword.shape[0], dtype=torch.uint8, device=DEV)
+        ops.embed_text_bwd_det(ids, seg, dz, dword, dpos, dtyp, B, T, H, pad, row_flags=flags)
+        outs.append((dword, dpos, dtyp, flags))
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a_, b_)
+    dword, dpos, dtyp, flags = outs[0]
+    keep = (ids.view(-1) != pad)
+    ref_w = base[0].double().index_add_(0, ids.view(-1)[keep], dz.double()[keep])
+    ref_p = base[1].double().index_add_(0, pos_ids, dz.double())
+    ref_t = base[2].double().index_add_(0, seg.view(-1), dz.double())
+    tol = 2e-6 * math.sqrt(R)
+    torch.testing.assert_close(dword.double(), ref_w, rtol=1e-6, atol=tol)
+    torch.testing.assert_close(dpos.double(), ref_p, rtol=1e-6, atol=tol * 4)
+    torch.testing.assert_close(dtyp.double(), ref_t, rtol=1e-6, atol=tol * 16)
+    touched = torch.zeros_like(flags)
+    touched[ids.view(-1)[keep]] = 1
+    assert torch.equal(flags, touched)
+
+
+def test_deterministic_loc_bwd_and_sumsq():
+    R, L, H = 9216, 7, 768
+    loc, dy = _rand(R, L, seed=33), _rand(R, H, seed=36)
+    res = []
+    for rep in range(2):
+        dw, db = torch.ones(H, L, device=DEV), torch.ones(H, device=DEV)
+        ops.loc_linear_bwd(loc, dy, dw, db, R, L, H, deterministic=True)
+        res.append((dw, db))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    torch.testing.assert_close(res[0][0].double(), 1.0 + dy.double().t() @ loc.double(), rtol=1e-5, atol=1e-3)
+    torch.testing.assert_close(res[0][1].double(), 1.0 + dy.double().sum(0), rtol=1e-5, atol=1e-3)
+    x = _rand(3_000_001, seed=44)
+    ws = torch.empty(2048, device=DEV)
+    o = [torch.full((1,), 2.0, device=DEV) for _ in range(3)]
+    ops.sumsq(x, o[0], ws=ws)
+    ops.sumsq(x, o[1], ws=ws)
+    assert torch.equal(o[0], o[1])
+    torch.testing.assert_close(o[0].double().cpu(), 2.0 + (x.double() ** 2).sum().view(1).cpu(), rtol=1e-5, atol=1e-3)
+
+
 def test_adamw_and_sumsq():
     n = 5000
     p, g = _rand(n, seed=37), _rand(n, seed=38)
