@@ -11,9 +11,14 @@
 // Q.K^T as Kh.Ql + Kl.Qh + Kh.Qh and P.V with P split in registers -- fp32-grade like the projections around it;
 // backward = single-pass bf16 on the hi halves, like every other backward product of the engine.
 //
-// One workgroup (4 waves) per (sample, head); K and V (forward) / Q, K, V, dO (backward) tiles live in LDS as
-// [row][64] bf16 with a 144-byte row pitch (conflict-free for ds_read_b128 operand reads and for the transposing
-// ds_read_b64_tr_b16 reads).  S <= 160: a query tile's whole key range lives in registers (plain softmax).
+// One workgroup per (sample, head) -- 4 waves for S <= 80, 8 waves beyond (at S = 120 / 140 the LDS tiles allow two
+// workgroups per CU: 16 resident waves instead of 8 / 4 of round 2) -- with K and V (forward) / Q, K, V, dO (backward) in LDS as
+// [row][64] bf16 at a 128-byte pitch, the 16-byte chunks of a row XOR-swizzled with sw(row) = ((row >> 1) & 3) << 1 |
+// (row >> 3) & 1: conflict-free for the ds_read_b128 operand reads (16 consecutive rows, one chunk), for the transposing
+// ds_read_b64_tr_b16 reads (8 rows x one 32-byte block) and for the staging stores; round 2's padded 144-byte pitch measured
+// 0.36 - 0.38 SQ_LDS_BANK_CONFLICT per active LDS cycle (rows r and r + 7 of a transposing read overlap by 4 banks) and
+// cost 12 % more LDS.  Head dim 32 (the tiny c1 config) keeps a padded 80-byte pitch.  S <= 160: a query tile's whole key
+// range lives in registers (plain softmax).
 //
 // Register-resident probabilities.  Scores are computed TRANSPOSED, S^T[key][query] = K.Q^T: the MFMA result layout
 // (lane: column = lane & 15, rows 4*(lane >> 4) + r) then gives a lane ONE query and 4 consecutive keys per key tile,
@@ -32,7 +37,17 @@ namespace {
 
 // head dim DH (64: the model configs; 32: the tiny "c1" plumbing config) is a template parameter: KS = DH / 32 k-steps
 // per Q.K^T product, DT = DH / 16 output column tiles, LDS row pitch DH * 2 + 16 bytes
-template <int DH> struct Geo { static constexpr int KS = DH / 32, DT = DH / 16, PITCH = DH * 2 + 16; };
+template <int DH> struct Geo {
+  static constexpr int KS = DH / 32, DT = DH / 16, PITCH = DH == 64 ? 128 : DH * 2 + 16;
+  // chunk swizzle of a row (16-byte chunks; 0 for the padded layout)
+  static __device__ __forceinline__ int sw(int row) { return DH == 64 ? ((((row >> 1) & 3) << 1) | ((row >> 3) & 1)) : 0; }
+  // byte offset of 16-byte chunk `chunk` of `row` (ds_read_b128 operand fragments, staging)
+  static __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * PITCH + ((chunk ^ sw(row)) << 4); }
+  // byte offset of this lane's 8 bytes of a transposing read: columns 16 dt + 4 pp .. + 3 of `row`
+  static __device__ __forceinline__ int tr_off(int row, int dt, int pp) {
+    return row * PITCH + (((2 * dt + (pp >> 1)) ^ sw(row)) << 4) + 8 * (pp & 1);
+  }
+};
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -95,14 +110,14 @@ __device__ __forceinline__ float keep_of(const Attn2Args& p, unsigned bits, int 
 }
 
 // stage rows [0, Spad) x DH bf16 of one matrix into an LDS tile (zeros beyond `rows`); src row pitch ld elements
-template <int DH>
+template <int DH, int NTHR>
 __device__ __forceinline__ void stage16(unsigned char* dst, const bf16_raw* src, long ld, int rows, int Spad, int tid) {
-  constexpr int CH = DH / 8, PITCH = Geo<DH>::PITCH;  // 16-byte chunks per row
-  for (int idx = tid; idx < Spad * CH; idx += 256) {
+  constexpr int CH = DH / 8;  // 16-byte chunks per row
+  for (int idx = tid; idx < Spad * CH; idx += NTHR) {
     const int row = idx / CH, c = idx - row * CH;
     uint4 v = make_uint4(0u, 0u, 0u, 0u);
     if (row < rows) v = *reinterpret_cast<const uint4*>(src + (long)row * ld + c * 8);
-    *reinterpret_cast<uint4*>(dst + row * PITCH + c * 16) = v;
+    *reinterpret_cast<uint4*>(dst + Geo<DH>::chunk_off(row, c)) = v;
   }
 }
 
@@ -111,14 +126,27 @@ __device__ __forceinline__ void stage16(unsigned char* dst, const bf16_raw* src,
 // ---------------------------------------------------------------------------------------------------------------
 // register budgets (workgroups per CU the allocation must allow), measured with tools/attn_bench.py: backward at S <= 128
 // gains 5 % from a third resident workgroup (197 -> 188 us at B = 256, S = 120), every other variant loses
-#ifndef VL_ATTN_FWD_MINWG
-#define VL_ATTN_FWD_MINWG(NT) 1
+// (second argument of __launch_bounds__ = waves per SIMD the register allocation must allow: NW = 8 waves x 2 workgroups per
+// CU = 4; the 4-wave instances keep round 2's budgets)
+// LDS admits two workgroups per CU up to 9 key tiles (S <= 144), one at 10: the register budgets follow
+#ifndef VL_ATTN_FWD_MINW
+#define VL_ATTN_FWD_MINW(NT, NW) ((NT) >= 10 ? (NW) / 4 : (NT) >= 8 ? (NW) / 2 : 1)
 #endif
-#ifndef VL_ATTN_BWD_MINWG
-#define VL_ATTN_BWD_MINWG(NT) ((NT) == 8 ? 3 : 1)
+#ifndef VL_ATTN_BWD_MINW
+#define VL_ATTN_BWD_MINW(NT, NW) ((NT) >= 10 ? (NW) / 4 : (NT) >= 8 ? ((NW) == 8 ? 2 : 2) : 1)
 #endif
-template <int NT, int DH>
-__global__ __launch_bounds__(256, VL_ATTN_FWD_MINWG(NT)) void attn2_fwd_kernel(Attn2Args p) {
+// waves per workgroup of the long-sequence instances, measured with tools/attn_bench.py at B = 256, dropout 0.1 (us, cold):
+//   forward  S = 120: 8 waves 128, 4 waves 150 | S = 140: 177 / 187 | S = 156 (B 128): 130 / 181          -> 8 waves
+//   backward S = 120: 8 waves 215, 4 waves 191 - 199 | S = 140: 313 / 257 - 263 | S = 156 (B 128): 174 / 259
+//            -> 4 waves while two workgroups fit a CU (<= 9 key tiles; 166 - 190 VGPRs rule out 2 x 8 waves), 8 beyond
+#ifndef VL_ATTN_FWD_NW
+#define VL_ATTN_FWD_NW 8
+#endif
+#ifndef VL_ATTN_BWD_NW
+#define VL_ATTN_BWD_NW(NT) ((NT) >= 10 ? 8 : 4)
+#endif
+template <int NT, int DH, int NW>
+__global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_kernel(Attn2Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int Spad = NT * 16, NP = (NT + 1) / 2;  // key-tile pairs
   constexpr int KS = Geo<DH>::KS, DT = Geo<DH>::DT, PITCH = Geo<DH>::PITCH;
@@ -133,16 +161,16 @@ __global__ __launch_bounds__(256, VL_ATTN_FWD_MINWG(NT)) void attn2_fwd_kernel(A
   const long ld = 3L * p.H;
   const bf16_raw* bh = p.qkv_hi + (long)b * S * ld + h * DH;
   const bf16_raw* bl = p.qkv_lo + (long)b * S * ld + h * DH;
-  stage16<DH>(sKh, bh + p.H, ld, S, Spad, tid);
-  stage16<DH>(sKl, bl + p.H, ld, S, Spad, tid);
-  stage16<DH>(sVh, bh + 2 * p.H, ld, S, Spad, tid);
-  stage16<DH>(sVl, bl + 2 * p.H, ld, S, Spad, tid);
-  for (int k = tid; k < Spad; k += 256) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
+  stage16<DH, NW * 64>(sKh, bh + p.H, ld, S, Spad, tid);
+  stage16<DH, NW * 64>(sKl, bl + p.H, ld, S, Spad, tid);
+  stage16<DH, NW * 64>(sVh, bh + 2 * p.H, ld, S, Spad, tid);
+  stage16<DH, NW * 64>(sVl, bl + 2 * p.H, ld, S, Spad, tid);
+  for (int k = tid; k < Spad; k += NW * 64) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
   const int l15 = lane & 15, g = lane >> 4, qq = l15 >> 2, pp = lane & 3;
   const int nqt = (p.nq + 15) >> 4;
   __syncthreads();
 
-  for (int qt = wave; qt < nqt; qt += 4) {
+  for (int qt = wave; qt < nqt; qt += NW) {
     const int q = qt * 16 + l15;
     // this lane's query row as the B operand of S^T = K.Q^T: Q[q][32 ks + 8 g ..]
     bf16x8 qh[KS], ql[KS];
@@ -160,10 +188,10 @@ __global__ __launch_bounds__(256, VL_ATTN_FWD_MINWG(NT)) void attn2_fwd_kernel(A
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       sc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const int off = (t * 16 + l15) * PITCH + 16 * g;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 kh = lds_frag(sKh + off + 64 * ks), kl = lds_frag(sKl + off + 64 * ks);
+        const int off = Geo<DH>::chunk_off(t * 16 + l15, g + 4 * ks);
+        const bf16x8 kh = lds_frag(sKh + off), kl = lds_frag(sKl + off);
         sc[t] = mfma(kh, ql[ks], sc[t]);
         sc[t] = mfma(kl, qh[ks], sc[t]);
         sc[t] = mfma(kh, qh[ks], sc[t]);
@@ -219,12 +247,13 @@ __global__ __launch_bounds__(256, VL_ATTN_FWD_MINWG(NT)) void attn2_fwd_kernel(A
       }
       bf16x8 ph, pl;
       pack8_split(pv, ph, pl);
-      const int r0 = (16 * t0 + 4 * g + qq) * PITCH + 8 * pp;
-      const int r1 = (16 * (t1 < NT ? t1 : t0) + 4 * g + qq) * PITCH + 8 * pp;  // (the slots of a missing tile hold p = 0)
+      const int vr0 = 16 * t0 + 4 * g + qq;
+      const int vr1 = 16 * (t1 < NT ? t1 : t0) + 4 * g + qq;  // (the slots of a missing tile hold p = 0)
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const bf16x8 vh = tr_frag2(sVh + r0 + 32 * dt, sVh + r1 + 32 * dt);
-        const bf16x8 vl = tr_frag2(sVl + r0 + 32 * dt, sVl + r1 + 32 * dt);
+        const int r0 = Geo<DH>::tr_off(vr0, dt, pp), r1 = Geo<DH>::tr_off(vr1, dt, pp);
+        const bf16x8 vh = tr_frag2(sVh + r0, sVh + r1);
+        const bf16x8 vl = tr_frag2(sVl + r0, sVl + r1);
         o[dt] = mfma(vh, pl, o[dt]);
         o[dt] = mfma(vl, ph, o[dt]);
         o[dt] = mfma(vh, ph, o[dt]);
@@ -252,8 +281,8 @@ __global__ __launch_bounds__(256, VL_ATTN_FWD_MINWG(NT)) void attn2_fwd_kernel(A
 // Phase A (a wave owns query tiles, transposed layout): delta and dQ.  Phase B (a wave owns key tiles, plain layout,
 // scores recomputed): dK and dV accumulate in registers over the query tiles.
 // ---------------------------------------------------------------------------------------------------------------
-template <int NT, int DH>
-__global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(Attn2Args p) {
+template <int NT, int DH, int NW>
+__global__ __launch_bounds__(NW * 64, VL_ATTN_BWD_MINW(NT, NW)) void attn2_bwd_kernel(Attn2Args p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   constexpr int Spad = NT * 16, NP = (NT + 1) / 2;
   constexpr int KS = Geo<DH>::KS, DT = Geo<DH>::DT, PITCH = Geo<DH>::PITCH;
@@ -269,11 +298,11 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
   const int S = p.S;
   const long ld = 3L * p.H;
   const bf16_raw* bh = p.qkv_hi + (long)b * S * ld + h * DH;
-  stage16<DH>(sQ, bh, ld, S, Spad, tid);
-  stage16<DH>(sK, bh + p.H, ld, S, Spad, tid);
-  stage16<DH>(sV, bh + 2 * p.H, ld, S, Spad, tid);
-  stage16<DH>(sO, p.dctx + (long)b * p.ctx_rows * p.H + h * DH, p.H, p.nq, Spad, tid);
-  for (int k = tid; k < Spad; k += 256) {
+  stage16<DH, NW * 64>(sQ, bh, ld, S, Spad, tid);
+  stage16<DH, NW * 64>(sK, bh + p.H, ld, S, Spad, tid);
+  stage16<DH, NW * 64>(sV, bh + 2 * p.H, ld, S, Spad, tid);
+  stage16<DH, NW * 64>(sO, p.dctx + (long)b * p.ctx_rows * p.H + h * DH, p.H, p.nq, Spad, tid);
+  for (int k = tid; k < Spad; k += NW * 64) {
     smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
     slse[k] = k < S ? p.lse[((long)b * p.nh + h) * S + k] : INFINITY;  // +inf -> P = 0 for padded queries
     sdelta[k] = 0.f;
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
   __syncthreads();
 
   // ---- phase A: delta and dQ (transposed layout: lane = one query, keys 16 t + 4 g + r) ------------------------
-  for (int qt = wave; qt < nqt_all; qt += 4) {
+  for (int qt = wave; qt < nqt_all; qt += NW) {
     const int q = qt * 16 + l15;
     if (qt >= nqt) {  // rows without a gradient: dQ = 0
       if (q < S) {
@@ -299,8 +328,8 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
     bf16x8 fq[KS], fo[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      fq[ks] = lds_frag(sQ + q * PITCH + 16 * g + 64 * ks);
-      fo[ks] = lds_frag(sO + q * PITCH + 16 * g + 64 * ks);
+      fq[ks] = lds_frag(sQ + Geo<DH>::chunk_off(q, g + 4 * ks));
+      fo[ks] = lds_frag(sO + Geo<DH>::chunk_off(q, g + 4 * ks));
     }
     const float lse_q = slse[q];
     f32x4 pv[NT], kd[NT];  // P and keep * dP
@@ -308,11 +337,11 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
-      const int off = (t * 16 + l15) * PITCH + 16 * g;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        s = mfma(lds_frag(sK + off + 64 * ks), fq[ks], s);
-        dp = mfma(lds_frag(sV + off + 64 * ks), fo[ks], dp);
+        const int off = Geo<DH>::chunk_off(t * 16 + l15, g + 4 * ks);
+        s = mfma(lds_frag(sK + off), fq[ks], s);
+        dp = mfma(lds_frag(sV + off), fo[ks], dp);
       }
       const float4 mk = *reinterpret_cast<const float4*>(smask + 16 * t + 4 * g);
       const float mkv[4] = {mk.x, mk.y, mk.z, mk.w};
@@ -349,10 +378,10 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
         dsv[4 + r] = has1 ? pv[t1][r] * (kd[t1][r] - delta) * p.scale : 0.f;
       }
       const bf16x8 dsb = pack8(dsv);
-      const int r0 = (16 * t0 + 4 * g + qq) * PITCH + 8 * pp;
-      const int r1 = (16 * t1 + 4 * g + qq) * PITCH + 8 * pp;
+      const int kr0 = 16 * t0 + 4 * g + qq, kr1 = 16 * t1 + 4 * g + qq;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) o[dt] = mfma(tr_frag2(sK + r0 + 32 * dt, sK + r1 + 32 * dt), dsb, o[dt]);
+      for (int dt = 0; dt < DT; ++dt)
+        o[dt] = mfma(tr_frag2(sK + Geo<DH>::tr_off(kr0, dt, pp), sK + Geo<DH>::tr_off(kr1, dt, pp)), dsb, o[dt]);
       asm volatile("" ::: "memory");
     }
     if (q < S) {
@@ -368,13 +397,13 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
 
   // ---- phase B: dK and dV (plain layout: lane = one key, queries 16 qt + 4 g + r) ------------------------------
   const int nqp = (nqt + 1) >> 1;  // query-tile pairs
-  for (int kt = wave; kt < NT; kt += 4) {
+  for (int kt = wave; kt < NT; kt += NW) {
     const int key = kt * 16 + l15;
     bf16x8 fk[KS], fv[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      fk[ks] = lds_frag(sK + key * PITCH + 16 * g + 64 * ks);
-      fv[ks] = lds_frag(sV + key * PITCH + 16 * g + 64 * ks);
+      fk[ks] = lds_frag(sK + Geo<DH>::chunk_off(key, g + 4 * ks));
+      fv[ks] = lds_frag(sV + Geo<DH>::chunk_off(key, g + 4 * ks));
     }
     const float mk = smask[key];
     f32x4 dK[DT], dV[DT];
@@ -387,11 +416,11 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
         const int qt = 2 * pq + half;
         if (qt < nqt) {
           f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = s;
-          const int off = (qt * 16 + l15) * PITCH + 16 * g;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            s = mfma(lds_frag(sQ + off + 64 * ks), fk[ks], s);
-            dp = mfma(lds_frag(sO + off + 64 * ks), fv[ks], dp);
+            const int off = Geo<DH>::chunk_off(qt * 16 + l15, g + 4 * ks);
+            s = mfma(lds_frag(sQ + off), fk[ks], s);
+            dp = mfma(lds_frag(sO + off), fv[ks], dp);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -409,12 +438,12 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
       }
       const bf16x8 bpd = pack8(pdv), bds = pack8(dsv);
       const int qt1 = (2 * pq + 1 < nqt) ? 2 * pq + 1 : 2 * pq;  // (the slots of a missing tile hold zeros)
-      const int r0 = (32 * pq + 4 * g + qq) * PITCH + 8 * pp;
-      const int r1 = (16 * qt1 + 4 * g + qq) * PITCH + 8 * pp;
+      const int qr0 = 32 * pq + 4 * g + qq, qr1 = 16 * qt1 + 4 * g + qq;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        dV[dt] = mfma(tr_frag2(sO + r0 + 32 * dt, sO + r1 + 32 * dt), bpd, dV[dt]);
-        dK[dt] = mfma(tr_frag2(sQ + r0 + 32 * dt, sQ + r1 + 32 * dt), bds, dK[dt]);
+        const int r0 = Geo<DH>::tr_off(qr0, dt, pp), r1 = Geo<DH>::tr_off(qr1, dt, pp);
+        dV[dt] = mfma(tr_frag2(sO + r0, sO + r1), bpd, dV[dt]);
+        dK[dt] = mfma(tr_frag2(sQ + r0, sQ + r1), bds, dK[dt]);
       }
     }
     if (key < S) {
@@ -431,37 +460,41 @@ __global__ __launch_bounds__(256, VL_ATTN_BWD_MINWG(NT)) void attn2_bwd_kernel(A
   }
 }
 
-template <int NT, int DH>
+template <int NT, int DH, int NW>
 int launch_fwd(const Attn2Args& a, hipStream_t s) {
   const size_t lds = (size_t)NT * 16 * (4 * Geo<DH>::PITCH + 4);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<NT, DH>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_fwd_kernel<NT, DH, NW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return vl_set_error(-3, "vl_attn2_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((attn2_fwd_kernel<NT, DH>), dim3(a.B * a.nh), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn2_fwd_kernel<NT, DH, NW>), dim3(a.B * a.nh), dim3(NW * 64), lds, s, a);
   VL_CHECK_LAUNCH("vl_attn2_fwd");
   return 0;
 }
-template <int NT, int DH>
+template <int NT, int DH, int NW>
 int launch_bwd(const Attn2Args& a, hipStream_t s) {
   const size_t lds = (size_t)NT * 16 * (4 * Geo<DH>::PITCH + 12);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_kernel<NT, DH>),
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn2_bwd_kernel<NT, DH, NW>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return vl_set_error(-3, "vl_attn2_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((attn2_bwd_kernel<NT, DH>), dim3(a.B * a.nh), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((attn2_bwd_kernel<NT, DH, NW>), dim3(a.B * a.nh), dim3(NW * 64), lds, s, a);
   VL_CHECK_LAUNCH("vl_attn2_bwd");
   return 0;
 }
+// key tiles NT (Spad = 16 NT) and waves per workgroup by sequence length; S in (128, 144] -- M3P's default 20 + 100 + ... = 140
+// -- has its own instance: with 9 tiles instead of 10 two workgroups fit a CU's LDS (73.7 KB each)
 template <int DH> int dispatch_fwd(const Attn2Args& a, hipStream_t s) {
-  if (a.S <= 64) return launch_fwd<4, DH>(a, s);
-  if (a.S <= 80) return launch_fwd<5, DH>(a, s);
-  if (a.S <= 128) return launch_fwd<8, DH>(a, s);
-  return launch_fwd<10, DH>(a, s);
+  if (a.S <= 64) return launch_fwd<4, DH, 4>(a, s);
+  if (a.S <= 80) return launch_fwd<5, DH, 4>(a, s);
+  if (a.S <= 128) return launch_fwd<8, DH, VL_ATTN_FWD_NW>(a, s);
+  if (a.S <= 144) return launch_fwd<9, DH, VL_ATTN_FWD_NW>(a, s);
+  return launch_fwd<10, DH, VL_ATTN_FWD_NW>(a, s);
 }
 template <int DH> int dispatch_bwd(const Attn2Args& a, hipStream_t s) {
-  if (a.S <= 64) return launch_bwd<4, DH>(a, s);
-  if (a.S <= 80) return launch_bwd<5, DH>(a, s);
-  if (a.S <= 128) return launch_bwd<8, DH>(a, s);
-  return launch_bwd<10, DH>(a, s);
+  if (a.S <= 64) return launch_bwd<4, DH, 4>(a, s);
+  if (a.S <= 80) return launch_bwd<5, DH, 4>(a, s);
+  if (a.S <= 128) return launch_bwd<8, DH, VL_ATTN_BWD_NW(8)>(a, s);
+  if (a.S <= 144) return launch_bwd<9, DH, VL_ATTN_BWD_NW(9)>(a, s);
+  return launch_bwd<10, DH, VL_ATTN_BWD_NW(10)>(a, s);
 }
 
 int fill_common(const char* fn, Attn2Args& a, int64_t B, int64_t S, int64_t nh, int64_t dh, int64_t nq, float p_drop,

@@ -24,7 +24,7 @@ def timeit(fn, n=30):
 
 
 def main():
-    for B, S in ((256, 56), (256, 120), (128, 120), (256, 140)):
+    for B, S in ((256, 56), (256, 76), (256, 120), (128, 120), (256, 140), (128, 156)):
         nh, H = 12, 768
         M = B * S
         qkv = torch.randn(M, 3 * H, device="cuda")
