@@ -459,15 +459,41 @@ __device__ __forceinline__ int swz3(int row) {
   return ((row >> 1) & 1) | (((row >> 3) & 1) << 1) | ((((row >> 4) ^ (row >> 2)) & 1) << 2);
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 3 || N == 4 || N == 5 || N == 6 || N == 7 || N == 8, "unsupported count");
-  if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  static_assert(N >= 0 && N <= 12, "unsupported count");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  if (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  if (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  if (N == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+  if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
+
+// RING (VL_GEMM_RING): LDS slots per operand, each one half-tile.  4 = two K-tiles resident (128 KB at 256 x 256): a half-tile
+// is issued 4 - 5 phases (one K-tile) before its first read.  5 = all 160 KB of the CU's LDS: every half-tile is issued TWO
+// PHASES EARLIER -- 7 - 8 phases before its read -- because the timing experiments (profiles/r03_ab_log.txt section 7) put 11 - 21 %
+// of every product into waits for operand DMA: one K-tile of prefetch distance is shorter than the memory latency of the
+// loaded chip.  Slot of half h of K-tile kt: (2 kt + h) mod RING, per operand.  Schedule for RING = 5, K-tile kt:
+//      phase 0: read B0, A0 (kt) | issue A0 (kt + 2)      phase 1: read B1 (kt) | issue B0 (kt + 2)
+//      phase 2: read A1 (kt)     | issue B1 (kt + 2)      phase 3:              | issue A1 (kt + 2)
+//  * WAR: A0 (kt + 2) takes the slot of A1 (kt - 1) (last read: phase 2 of kt - 1), B0 (kt + 2) that of B1 (kt - 1) (phase 1 of
+//    kt - 1), B1 (kt + 2) that of B0 (kt) (phase 0), A1 (kt + 2) that of A0 (kt) (phase 0): always >= 2 phases after the read,
+//    the same margin as the 4-slot ring.
+//  * RAW: after its own issue every phase waits until at most the SIX youngest half-tiles are outstanding, so a half-tile
+//    issued in phase q has landed by the wait of phase q + 6 and is first read in phase q + 7 or q + 8, behind the barriers of
+//    phase q + 6 (also with the one-barrier stagger of waves 4 - 7).
+// Measured (same box, profiles/r03_ab_log.txt section 9): no difference -- QKV 140.2 / 141.2 vs 150.4 / 138.6 us, FFN2 215 / 208 vs
+// 205 / 210, step 16.07 / 16.13 vs 16.10 / 16.09 ms.  The cost the "no DMA" experiment exposes is therefore NOT prefetch distance
+// (the data is there in time); the 4-slot ring stays the default (128 KB), the 5-slot path stays tested behind the macro.
+#ifndef VL_GEMM_RING
+#define VL_GEMM_RING 4
+#endif
 
 // PERSIST: the grid is a fixed number of workgroups G (<= the CU count); workgroup w runs tiles w, w + G, w + 2G, ... (the
 // XCD-contiguous tile order is kept: tile t and t + G land on the same XCD when G % 8 == 0).  Between two tiles the DMA
@@ -491,6 +517,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   constexpr int KSTEP = NSPLIT == 3 ? 32 : 64;
   constexpr bool PAIR = (EPI != VL_EPI_F32);
   constexpr int NJP = PAIR ? (NJ & ~1) : 0;                 // n-tiles [0, NJP) of a quadrant are paired
+  constexpr int RING = VL_GEMM_RING;                        // LDS slots per operand (see above)
+  constexpr int SLOT_A = AH * 128, SLOT_B = BH * 128;       // RING == 5: A ring at 0, B ring behind it
+  constexpr int RING_B0 = RING * SLOT_A;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -551,6 +580,25 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     if (issued) G3_WAIT_YOUNGER(2, 2);                                                                           \
     else wait_vmcnt<0>();                                                                                        \
   } while (0)
+  // RING == 5: half-tile x of K-tile kt into ring slot `slot` (a scalar) of its operand
+#define G5_ISSUE(x, kt, slot)                                                                                    \
+  do {                                                                                                           \
+    unsigned char* dst_ = smem + ((x) >= 2 ? RING_B0 + (slot) * SLOT_B : (slot) * SLOT_A);                       \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][0] + (long)(kt) * KSTEP), (lds_ptr_t)(dst_ + wave * 1024), 16, 0, 0); \
+    if (!(late && ((BSHORT && (x) >= 2) || (ASHORT && (x) == 1))))                                               \
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[x][1] + (long)(kt) * KSTEP), (lds_ptr_t)(dst_ + (wave + 8) * 1024), 16, 0, 0); \
+  } while (0)
+  // ... wait until at most the youngest (nA0 first-half A + nA1 second-half A + nB B) half-tiles are outstanding
+#define G5_WAIT_YOUNGER(nA0, nA1, nB)                                                                            \
+  do {                                                                                                           \
+    if (late) wait_vmcnt<2 * (nA0) + (ASHORT ? 1 : 2) * (nA1) + (BSHORT ? 1 : 2) * (nB)>();                      \
+    else wait_vmcnt<2 * ((nA0) + (nA1) + (nB))>();                                                               \
+  } while (0)
+#define G5_WAIT(issued, nA0, nA1, nB)                                                                            \
+  do {                                                                                                           \
+    if (issued) G5_WAIT_YOUNGER(nA0, nA1, nB);                                                                   \
+    else wait_vmcnt<0>();                                                                                        \
+  } while (0)
 
   f32x4 acc[2][2][MI][NJ];  // [1][*][i >= MI1] unused
 
@@ -589,6 +637,16 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     fb[j][0] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][0]);                  \
     fb[j][1] = *reinterpret_cast<const bf16x8*>((st) + OFF_B0 + (qn) * (BH * 128) + b_o[j][1]);                  \
   }
+#define G5_READ_A(pa, qm)                                                                                        \
+  G3_RD_GUARD _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i) {                              \
+    fa[i][0] = *reinterpret_cast<const bf16x8*>((pa) + a_o[(qm) % QA][i][0]);                                    \
+    fa[i][1] = *reinterpret_cast<const bf16x8*>((pa) + a_o[(qm) % QA][i][1]);                                    \
+  }
+#define G5_READ_B(pb, fb)                                                                                        \
+  G3_RD_GUARD _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                  \
+    fb[j][0] = *reinterpret_cast<const bf16x8*>((pb) + b_o[j][0]);                                               \
+    fb[j][1] = *reinterpret_cast<const bf16x8*>((pb) + b_o[j][1]);                                               \
+  }
   // 1 pass: [0] / [1] are the two 32-deep k halves of the row; 3 passes: [0] = hi, [1] = lo of one 32-deep k step and
   // the products are issued product-major so that dependent accumulations are MI*NJ MFMAs apart
 #define G3_MFMA(qm, qn, fb)                                                                                      \
@@ -619,14 +677,20 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   } while (0)
 
   // prologue: K-tile 0 complete, A0 / B0 of K-tile 1 in flight
+  // (RING == 5: K-tile 0 complete, ALL of K-tile 1 in flight, issued in the loop's order A0, B0, B1, A1)
 #define G3_PROLOGUE_ISSUE()                                                                                      \
   do {                                                                                                           \
-    G3_ISSUE(0, 0); G3_ISSUE(2, 0); G3_ISSUE(3, 0); G3_ISSUE(1, 0);                                              \
-    if (nk > 1) { G3_ISSUE(0, 1); G3_ISSUE(2, 1); }                                                              \
+    if (RING == 5) {                                                                                             \
+      G5_ISSUE(0, 0, 0); G5_ISSUE(2, 0, 0); G5_ISSUE(3, 0, 1); G5_ISSUE(1, 0, 1);                                \
+      if (nk > 1) { G5_ISSUE(0, 1, 2); G5_ISSUE(2, 1, 2); G5_ISSUE(3, 1, 3); G5_ISSUE(1, 1, 3); }                \
+    } else {                                                                                                     \
+      G3_ISSUE(0, 0); G3_ISSUE(2, 0); G3_ISSUE(3, 0); G3_ISSUE(1, 0);                                            \
+      if (nk > 1) { G3_ISSUE(0, 1); G3_ISSUE(2, 1); }                                                            \
+    }                                                                                                            \
   } while (0)
 #define G3_PROLOGUE_WAIT()                                                                                       \
   do {                                                                                                           \
-    if (nk > 1) G3_WAIT_YOUNGER(1, 1);                                                                           \
+    if (nk > 1) { if (RING == 5) G5_WAIT_YOUNGER(1, 1, 2); else G3_WAIT_YOUNGER(1, 1); }                          \
     else wait_vmcnt<0>();                                                                                        \
     __builtin_amdgcn_s_barrier();                                                                                \
     if (late) __builtin_amdgcn_s_barrier(); /* stagger */                                                        \
@@ -650,6 +714,41 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 #if defined(VL_EXP_NO_DMA) || defined(VL_EXP_NO_READS)
 #pragma message("gemm3_kernel: timing-experiment build -- results are wrong")
 #endif
+  if constexpr (RING == 5) {
+    int ia = 0, ib = 0;  // ring slots of A0 (kt) / B0 (kt): (2 kt) mod 5
+    for (int kt = 0; kt < nk; ++kt) {
+#ifdef VL_EXP_NO_DMA
+      const bool n2 = false;
+#else
+      const bool n2 = kt + 2 < nk;
+#endif
+      const int ia1 = ia + 1 >= 5 ? ia - 4 : ia + 1, ia4 = ia + 4 >= 5 ? ia - 1 : ia + 4;  // slots of A1 (kt), A0 (kt + 2)
+      const int ib1 = ib + 1 >= 5 ? ib - 4 : ib + 1, ib4 = ib + 4 >= 5 ? ib - 1 : ib + 4;  //          B1 (kt), B0 (kt + 2)
+      // phase 0: quadrant (0,0)
+      G5_READ_B(smem + RING_B0 + ib * SLOT_B, fb0);
+      __builtin_amdgcn_sched_barrier(0);
+      G5_READ_A(smem + ia * SLOT_A, 0);
+      if (n2) G5_ISSUE(0, kt + 2, ia4);
+      G5_WAIT(n2, 2, 2, 2);
+      G3_MFMA(0, 0, fb0);
+      // phase 1: quadrant (0,1)
+      G5_READ_B(smem + RING_B0 + ib1 * SLOT_B, fb1);
+      if (n2) G5_ISSUE(2, kt + 2, ib4);
+      G5_WAIT(n2, 2, 1, 3);
+      G3_MFMA(0, 1, fb1);
+      // phase 2: quadrant (1,1)
+      G5_READ_A(smem + ia1 * SLOT_A, 1);
+      if (n2) G5_ISSUE(3, kt + 2, ib);  // (B1 (kt + 2): the slot B0 (kt) was read from in phase 0)
+      G5_WAIT(n2, 1, 1, 4);
+      G3_MFMA(1, 1, fb1);
+      // phase 3: quadrant (1,0)
+      if (n2) G5_ISSUE(1, kt + 2, ia);  // (A1 (kt + 2): the slot of A0 (kt))
+      G5_WAIT(n2, 1, 2, 3);
+      G3_MFMA(1, 0, fb0);
+      ia = ia + 2 >= 5 ? ia - 3 : ia + 2;
+      ib = ib + 2 >= 5 ? ib - 3 : ib + 2;
+    }
+  } else {
   for (int kt = 0; kt < nk; ++kt) {
     const unsigned char* st = smem + (kt & 1) * STAGE;
 #ifdef VL_EXP_NO_DMA
@@ -678,6 +777,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
     if (n2) G3_ISSUE(2, kt + 2);
     G3_WAIT(n2);
     G3_MFMA(1, 0, fb0);
+  }
   }
   if (!late) __builtin_amdgcn_s_barrier();  // matches the stagger barrier
   // the finished tile's coordinates for the epilogue; then (PERSIST) the next tile's DMA prologue goes out first
@@ -801,6 +901,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
 #undef G3_MFMA
 #undef G3_PROLOGUE_ISSUE
 #undef G3_PROLOGUE_WAIT
+#undef G5_ISSUE
+#undef G5_WAIT_YOUNGER
+#undef G5_WAIT
+#undef G5_READ_A
+#undef G5_READ_B
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1249,7 +1354,8 @@ int launch3p(const GemmArgs& a, int grid, size_t lds, hipStream_t stream) {
 template <int NSPLIT, int EPI, int CFG>
 int launch3(GemmArgs a, hipStream_t stream) {
   constexpr int BMT = CFG == 2 ? 224 : 256, BNT = CFG == 1 ? 192 : 256;
-  const size_t lds = 2 * (BMT + BNT) * 128;
+  // two K-tiles of both operands, or (VL_GEMM_RING == 5) five half-tile slots per operand: 160 KB at 256 x 256, all of a CU's LDS
+  const size_t lds = VL_GEMM_RING == 5 ? 5 * (128 + BNT / 2) * 128 : 2 * (BMT + BNT) * 128;
   a.tiles_m = (a.M + BMT - 1) / BMT;
   a.tiles_n = (a.N + BNT - 1) / BNT;
   tl_cs_rows = a.tiles_m * 2 * (CFG == 1 ? 4 : 2);  // column-sum partial rows this configuration writes
