@@ -299,6 +299,10 @@ def main():
                      max_grad_norm=1.0, warmup_steps=100, t_total=100000,
                      overlap_reduce=False if os.environ.get("BENCH_LAYER_HOOK", "1") == "0" else None)
     opt.flag_sumsq = os.environ.get("BENCH_FLAG_SUMSQ", "1") != "0"
+    # A/B: BENCH_PIPELINE_UPDATE=1 = the optimizer update of step i runs chunk by chunk under the forward of step i + 1 (the last
+    # step's update stays inside the timed region: the closing synchronize waits for it).  Measured neutral (15.90 / 15.92 vs
+    # 15.84 / 16.00 ms: the forward GEMMs slow down by what the hidden update saves) -> off
+    opt.pipeline_update = os.environ.get("BENCH_PIPELINE_UPDATE", "0") == "1"
     # NBATCH synthetic batches resident in HBM, rotated through the loop: every step sees other token ids (another set of
     # touched word-embedding rows for the sparse optimizer path) and other features (no step re-reads what the last one left
     # in the Infinity Cache)

@@ -172,6 +172,10 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
   for (int64_t l = layer_begin; l < layer_end; ++l) {
     const int64_t* y = d + VL_ST_FIELDS + l * VL_LY_FIELDS;
     const int s3 = (int)(16 * l + 3);
+    if (y[VL_LY_EV_READY]) {  // this layer's parameters are being updated on another stream: wait for that update
+      hipError_t e = hipStreamWaitEvent((hipStream_t)stream, ptr<ihipEvent_t>(y[VL_LY_EV_READY]), 0);
+      if (e != hipSuccess) return vl_set_error(-3, "vl_stack_fwd: wait for layer %lld's parameters: %s", (long long)l, hipGetErrorString(e));
+    }
     // only the pooled row of every sample leaves the LAST layer (BertTextPooler reads hidden_states[:, 0],
     // encoders.py:597-608; M3P's BertPooler likewise): everything after the K/V projection of that layer runs on the
     // B live rows (R), in compact [B, .] buffers, with the dropout counters / row masks of the original rows (stride S)

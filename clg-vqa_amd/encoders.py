@@ -371,6 +371,10 @@ class BertForVLTasks(PreTrainedModel):
         self._engine.grad_mode = torch.is_grad_enabled()
         x = UC2TrunkFunction.apply(self._engine, self.training, input_txt, input_imgs, image_loc, token_type_ids,
                                    attention_mask, image_attention_mask, *params)
+        if self._engine.chunks_pending:  # a pipelined optimizer update: the heads' parameters are its last chunk
+            self._engine.wait_chunk(self._engine.n_chunks() - 1)
+            self._engine.chunks_pending = False
+            self._engine.stack.layer_ready_events = None
         head = self._task_head(task_id)
         if head.supported:  # pooler -> dropout -> classifier as one native autograd node (head.py)
             vil_prediction = head(x, self.training)

@@ -334,6 +334,7 @@ class LayerStack(object):
         # native node its window (~0.3 ms) no longer hides 12 layers of re-layout (0.78 ms); measured at c2, same box:
         # 0 -> 17.28, 6 -> 17.11, 8 -> 17.04, 11 -> 16.98, 12 -> 17.02 ms / step
         self.tr_bwd_layers = None
+        self.layer_ready_events = None  # per-layer torch.cuda.Event the forward waits for (pipelined optimizer update)
         self.layer_done_hook = None  # callable(layer, grads in LayerSpec.params order, stream) -> consumed?
         # callable(layer) -> (16 destination views in LayerSpec.params order, accumulate) or None: when the optimizer
         # provides it, gradients are written straight into its flat arena
@@ -460,6 +461,10 @@ class LayerStack(object):
         d[VL["VL_ST_DW_ROWMAJOR"]] = int(self.dw_rowmajor)
         d[VL["VL_ST_DX_TILE"]] = int(self.dx_tile)
         d[VL["VL_ST_GEMM_PERSIST"]] = int(self.gemm_persist[0]) | (int(self.gemm_persist[1]) << 16)
+        evs = self.layer_ready_events  # set by the engine when an optimizer update is running under this forward
+        F_, LF_ = VL["VL_ST_FIELDS"], VL["VL_LY_FIELDS"]
+        for l in range(len(self.specs)):
+            d[F_ + l * LF_ + VL["VL_LY_EV_READY"]] = 0 if evs is None else evs[l].cuda_event
         if ar.need_grad and self.dw_budget > 0:
             if ar.dw_sk_ws is None or ar.dw_sk_budget != self.dw_budget:
                 ar.dw_sk_ws, ar.dw_sk_budget = ops.dw_streamk_ws(self.dw_budget, ar.x32.device), self.dw_budget
@@ -578,10 +583,51 @@ class EngineBase(object):
         self.grad_mode = True  # torch.is_grad_enabled() at the model's call site (set by the module's forward)
         self._seed0 = 0
         self._last_arena = None
+        # optimizer update under the next forward (FusedAdamW.pipeline_update): the update + weight preparation of chunk c
+        # (0 = embeddings, 1 + l = layer l, last = task heads) runs on `update_stream`; the forward waits for chunk_events[c]
+        self.supports_update_pipeline = False
+        self._update_stream = None
+        self.chunk_events = None
+        self.chunks_pending = False
+        self._skip_prep_once = False
 
     def mark_dirty(self):
         """Call after updating parameters through raw pointers (the fused optimizer does)."""
         self._dirty = True
+
+    # ---- optimizer update under the next forward ---------------------------------------------------------------------
+    def update_stream(self, dev):
+        if self._update_stream is None or self._update_stream.device != dev:
+            self._update_stream = torch.cuda.Stream(device=dev)
+        return self._update_stream
+
+    def n_chunks(self):
+        return len(self.stack.specs) + 2
+
+    def chunk_tables(self):
+        """Per-chunk weight-preparation tables (built with the one-launch table by prepared()), or None before that."""
+        return None if self._prepared is None else self._prepared.get("chunks")
+
+    def prepare_chunk(self, c):
+        """Weight preparation + packed-bias copies of chunk c on the CURRENT native / torch stream."""
+        ch = self._prepared["chunks"][c]
+        if ch["nrows"]:
+            ops.weight_prep_multi(ch["table"], ch["nrows"], ch["tiles"])
+        if ch["bias_dst"]:
+            torch._foreach_copy_(ch["bias_dst"], ch["bias_src"])
+
+    def finish_prepare(self):
+        """All chunks were prepared by the optimizer: the next forward only waits for their events."""
+        pw = self._prepared
+        for p_ in pw["all_pw"]:
+            p_.refresh_bias(fingerprint=False, pack=False)
+        self._dirty = False
+        self._skip_prep_once = True
+        self.chunks_pending = True
+
+    def wait_chunk(self, c):
+        if self.chunks_pending and self.chunk_events is not None:
+            torch.cuda.current_stream().wait_event(self.chunk_events[c])
 
     def _push_word_grad(self, ids, rows, pad_id):
         rows = rows * (ids != pad_id).to(rows.dtype).unsqueeze(1)  # the pad row receives no gradient
@@ -630,6 +676,12 @@ class EngineBase(object):
             self._dirty = True
         pw = self._prepared
         all_pw = [pw["img"]] + [lw[k] for lw in pw["layers"] for k in ("qkv", "o", "w1", "w2")] + pw["head"]
+        pw["all_pw"] = all_pw
+        if self._skip_prep_once and not self._dirty:
+            # the optimizer prepared every chunk on the update stream (finish_prepare): nothing to launch, nothing to
+            # fingerprint; the forward waits for the chunk events
+            self._skip_prep_once = False
+            return pw
         explicit = self._dirty  # set by the optimizer every step: no need to fingerprint versions to find that out
         if explicit or any(p._key() != p.key for p in all_pw):
             # the device table only depends on where the source weights / masks live: compare those pointers first
@@ -646,6 +698,18 @@ class EngineBase(object):
                 # at the step boundary
                 pairs = [pr for p in all_pw for pr in p.bias_pairs()]
                 pw["bias_dst"], pw["bias_src"] = [d for d, _ in pairs], [s_ for _, s_ in pairs]
+                # the same table cut into chunks (embeddings | layer l | heads) for the optimizer's pipelined update
+                groups = [[pw["img"]]] + [[lw[k] for k in ("qkv", "o", "w1", "w2")] for lw in pw["layers"]] + [pw["head"]]
+                chunks = []
+                for grp in groups:
+                    rws, t0 = [], 0
+                    for r in (r for p in grp for r in p.descriptors()):
+                        rws.append(r + [t0])
+                        t0 += ((r[5] + 63) // 64) * ((r[6] + 63) // 64)
+                    prs = [pr for p in grp for pr in p.bias_pairs()]
+                    chunks.append(dict(table=torch.tensor(rws, dtype=torch.int64).to(device) if rws else None, nrows=len(rws),
+                                       tiles=t0, bias_dst=[d for d, _ in prs], bias_src=[s_ for _, s_ in prs]))
+                pw["chunks"] = chunks
             ops.weight_prep_multi(pw["table"], pw["table"].shape[0], pw["table_tiles"])  # one launch per step
             if pw["bias_dst"]:  # one multi-tensor copy
                 torch._foreach_copy_(pw["bias_dst"], pw["bias_src"])
@@ -665,6 +729,7 @@ class UC2Engine(EngineBase):
         self.n_layers = len(model.bert.encoder.layer) // 2
         self._init_common(self.H, self.nh)
         self.embed_overlap = True  # token / box-location embeddings on the side stream beside the feature projection
+        self.supports_update_pipeline = True
         specs = []
         for l in range(self.n_layers):
             at = model.bert.encoder.layer[2 * l]
@@ -714,6 +779,10 @@ class UC2Engine(EngineBase):
         p_att = float(cfg.attention_probs_dropout_prob) if training else 0.0
         seed0, seed = self.next_seed()
         pw = self.prepared(dev)
+        # (an optimizer update may still be running on the update stream: embeddings wait for chunk 0, every layer of the
+        # stack for its own chunk, the task head for the last one)
+        self.wait_chunk(0)
+        self.stack.layer_ready_events = self.chunk_events[1:-1] if self.chunks_pending and self.chunk_events else None
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)  # noqa: E731
         b16 = lambda *s: torch.empty(*s, dtype=BF16, device=dev)  # noqa: E731
         ids = ids.contiguous(); seg = seg.contiguous()

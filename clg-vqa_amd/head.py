@@ -96,6 +96,9 @@ class HeadFunction(torch.autograd.Function):
         dev = x.device
         need_grad = eng.grad_mode and any(ctx.needs_input_grad)
         ar = head.arena(B, dev)
+        if eng.chunks_pending:  # the optimizer update of the head's parameters may still be running (engine.wait_chunk)
+            eng.wait_chunk(eng.n_chunks() - 1)
+            eng.chunks_pending = False  # the forward has now waited for every chunk
         pwp, pw1, pw2 = (lin._vl_prepared(dev) for lin in (head.pooler, head.fc1, head.fc2))
         p = float(head.dropout.p) if training else 0.0
         seed = eng.last_seed(HEAD_SEED_SITE) if p > 0.0 else 0

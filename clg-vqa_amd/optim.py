@@ -165,7 +165,7 @@ class FusedAdamW(object):
     """AdamW(correct_bias) + clip + LR schedule + zero-grad as two kernels over the flat arena."""
 
     def __init__(self, model, base_lr=4e-5, weight_decay=1e-4, betas=(0.9, 0.999), eps=1e-6, correct_bias=True,
-                 max_grad_norm=1.0, warmup_steps=0, t_total=None, reducer=None, overlap_reduce=None):
+                 max_grad_norm=1.0, warmup_steps=0, t_total=None, reducer=None, overlap_reduce=None, pipeline_update=False):
         params = list(model.named_parameters())
         device = params[0][1].device
         if device.type != "cuda":
@@ -213,6 +213,15 @@ class FusedAdamW(object):
         # multi-GPU: all-reduce each transformer layer's gradients as soon as that layer's backward is enqueued
         # (needs one optimizer step per backward: pass overlap_reduce=False when accumulating gradients)
         self._pre, self._works, self._layer_plan = set(), [], None
+        # the update (AdamW + weight preparation) of chunk c = embeddings | layer l | heads on the engine's update stream, the
+        # NEXT forward waiting chunk by chunk: 0.6 + 0.2 ms of HBM-bound work per step run under the MFMA-bound forward GEMMs
+        # instead of in front of them (the clip norm needs every gradient, so nothing can start before backward has ended).
+        # OPT-IN: with it the parameters are final on the caller's stream only after the next forward of the model or after
+        # wait_update() -- a training loop that owns its schedule (train_task.py, bench.py) switches it on and calls
+        # wait_update() before it reads parameters itself (checkpoints, evaluation outside the model's forward, logging)
+        self.pipeline_update = bool(pipeline_update)
+        self._chunks = None
+        self._ev_start = None
         self.keep_reduced_grad = False
         self.flag_sumsq = True
         if overlap_reduce is None:
@@ -264,6 +273,40 @@ class FusedAdamW(object):
         return dict(wait_ms_per_step=round(wait, 4), dense_bytes_per_step=o["dense"] // o["steps"],
                     sparse_bytes_per_step=o["sparse"] // o["steps"], collectives_per_step=round(o["colls"] / o["steps"], 1))
 
+    def _update_chunks(self, eng):
+        """[(elem lo, elem hi, seg lo, seg hi, rebased seg_end on the device)] per chunk, or False when the arena order does
+        not allow it (a chunk's parameters are not one contiguous run of segments, in chunk order)."""
+        if self._chunks is not None:
+            return self._chunks
+        self._chunks = False
+        if not getattr(eng, "supports_update_pipeline", False):
+            return False
+        chunk_of = {}
+        for p_ in eng.param_list()[:len(eng.param_list()) - 16 * len(eng.stack.specs)]:
+            chunk_of[id(p_)] = 0
+        for l, sp in enumerate(eng.stack.specs):
+            for p_ in sp.params():
+                chunk_of[id(p_)] = 1 + l
+        last = eng.n_chunks() - 1
+        ids = [chunk_of.get(id(g[1]), last) for g in self.groups]
+        if any(b < a_ for a_, b in zip(ids, ids[1:])):  # chunk ids must be non-decreasing along the arena
+            return False
+        ends = [off + (g[1].numel() + 3) // 4 * 4 for g, off in zip(self.groups, self.arena.offsets)]
+        chunks, i = [], 0
+        for c in range(last + 1):
+            j = i
+            while j < len(ids) and ids[j] == c:
+                j += 1
+            if j == i:
+                chunks.append(None)  # nothing trainable in this chunk (frozen)
+                continue
+            lo, hi = self.arena.offsets[i], ends[j - 1]
+            seg_end = torch.tensor([e - lo for e in ends[i:j]], dtype=torch.int64, device=self.arena.param.device)
+            chunks.append((lo, hi, i, j, seg_end))
+            i = j
+        self._chunks = chunks
+        return chunks
+
     def set_overlap(self, enabled):
         """Switch the during-backward gradient exchange on / off (off: everything is reduced inside step())."""
         eng = getattr(self.model, "engine", None)
@@ -309,7 +352,52 @@ class FusedAdamW(object):
         self._pre.update(idx)
         return True
 
+    def wait_update(self):
+        """Make the current stream wait for a pipelined update still running on the engine's update stream."""
+        eng = getattr(self.model, "engine", None)
+        if eng is not None and eng.chunk_events is not None:
+            torch.cuda.current_stream().wait_event(eng.chunk_events[-1])  # (chunks are recorded in order on one stream)
+
+    def _step_pipelined(self, a, eng, chunks, seg_step, nxt, kw):
+        """AdamW + weight preparation chunk by chunk on the engine's update stream; the next forward waits per chunk."""
+        dev = a.param.device
+        main = torch.cuda.current_stream()
+        upd = eng.update_stream(dev)
+        if eng.chunk_events is None:
+            eng.chunk_events = [torch.cuda.Event() for _ in range(eng.n_chunks())]
+            for e in eng.chunk_events:
+                e.record()  # materialises the hipEvent_t handles the native stack waits on
+        if self._ev_start is None:
+            self._ev_start = torch.cuda.Event()
+        self._ev_start.record(main)  # gradients complete, clip norm accumulated
+        upd.wait_event(self._ev_start)
+        lr_mult = self.lr_mult()
+        flags = self._flag_args()
+        ops.set_stream(upd.cuda_stream)
+        try:
+            with torch.cuda.stream(upd):
+                first = True
+                for c, ch in enumerate(chunks):
+                    if ch is not None:
+                        lo, hi, i, j, seg_end = ch
+                        fl = {}
+                        if flags and lo <= flags["flag_begin"] < hi:
+                            fl = dict(flags, flag_begin=flags["flag_begin"] - lo)
+                        ops.adamw(a.param[lo:hi], a.grad[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], seg_end,
+                                  self.seg_lr[i:j], self.seg_wd[i:j], self.betas[0], self.betas[1], self.eps, self.opt_step,
+                                  self.correct_bias, lr_mult, sumsq_next=nxt if first else None,
+                                  seg_step=None if seg_step is None else seg_step[i:j], **kw, **fl)
+                        first = False
+                    eng.prepare_chunk(c)
+                    eng.chunk_events[c].record(upd)
+        finally:
+            ops.set_stream(None)
+        if hasattr(self.model, "mark_weights_dirty"):
+            self.model.mark_weights_dirty()  # (module-level Linears outside the engine re-prepare themselves)
+        eng.finish_prepare()
+
     def state_dict(self):
+        self.wait_update()
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "opt_step": self.opt_step,
                 "seg_steps": list(self.seg_steps), "sched_step": self.sched_step, "names": [g[0] for g in self.groups],
                 "row_flags": self.row_flags}
@@ -464,10 +552,15 @@ class FusedAdamW(object):
             self._seg_step_dev = torch.tensor(self.seg_steps, dtype=torch.int64).to(a.param.device)
             seg_step = self._seg_step_dev
         max_norm = self.max_grad_norm if self.max_grad_norm is not None else float("inf")
+        kw = dict(sumsq=cur, max_norm=min(max_norm, 3.0e38), post=post, zero_grad=True)
+        chunks = self._update_chunks(eng) if (self.pipeline_update and eng is not None) else False
+        if chunks and eng.chunk_tables() is not None:
+            self._step_pipelined(a, eng, chunks, seg_step, nxt, kw)
+            self.sched_step += 1
+            return norm
         ops.adamw(a.param, a.grad, self.exp_avg, self.exp_avg_sq, self.seg_end, self.seg_lr, self.seg_wd,
                   self.betas[0], self.betas[1], self.eps, self.opt_step, self.correct_bias, self.lr_mult(),
-                  sumsq=cur, max_norm=min(max_norm, 3.0e38), post=post, sumsq_next=nxt, zero_grad=True, seg_step=seg_step,
-                  **self._flag_args())
+                  sumsq_next=nxt, seg_step=seg_step, **kw, **self._flag_args())
         self.sched_step += 1
         if hasattr(self.model, "mark_weights_dirty"):
             self.model.mark_weights_dirty()

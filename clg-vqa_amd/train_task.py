@@ -193,7 +193,11 @@ def main(argv=None):
                           max_grad_norm=args.clip_grad_norm if args.clip_grad_norm > 0 else float("inf"),
                           warmup_steps=warm, t_total=t_total,
                           # gradients are exchanged during backward unless micro-batches are accumulated
-                          overlap_reduce=None if args.grad_acc_steps == 1 else False)
+                          overlap_reduce=None if args.grad_acc_steps == 1 else False,
+                          # (pipeline_update=True would run the update of step i under the forward of step i + 1 -- safe in
+                          # this loop, which reads parameters itself only behind the synchronize that closes an epoch -- but
+                          # it measures neutral at c2: profiles/r03_ab_log.txt section 10)
+                          pipeline_update=False)
 
     opt = new_optimizer()
     _, global_step, start_epoch, _, max_score = train_utils.resume(args.resume_file, model, opt, None, None)

@@ -362,6 +362,9 @@ enum {
                       epilogue of the FFN1-backward GEMM on the MAIN stream while the side stream may still read the layer
                       above's (0 = use the shared VL_ST_T_DU / VL_ST_CS_U through the re-layout pass) */
   VL_LY_CS_DU = 82,
+  VL_LY_EV_READY = 83, /* a hipEvent_t of the caller or 0: vl_stack_fwd makes its stream wait for it before the layer's first
+                          kernel (the layer's parameters / prepared weights are being written on another stream: the optimizer
+                          update of the previous step running under this forward) */
   VL_LY_FIELDS = 96
 };
 /* Pooled-row mode (VL_ST_POOLED_ONLY): the head reads hidden_states[:, 0] only (BertTextPooler, encoders.py:597-608; M3P

@@ -350,6 +350,42 @@ def test_training_steps_are_bit_reproducible_from_seed_and_call_count():
     assert not torch.equal(runs[0][0][2], runs[0][2][2])  # the parameters did move
 
 
+def test_pipelined_optimizer_update_equals_the_single_launch_update():
+    """FusedAdamW.pipeline_update: AdamW + weight preparation chunk by chunk (embeddings | layer l | heads) on the update
+    stream while the next forward starts, each layer waiting for its own chunk -- against the whole update in front of the
+    forward: losses and parameters after every step must be bit-equal (same kernels on sub-ranges of the same arenas)."""
+    from clg_vqa_amd.optim import FusedAdamW
+    config = BertConfig.from_dict(uc2_cfg_dict(n_layers=3, vocab=300))
+    batches = [make_batch(16, vocab_size=300, seed=170 + i) for i in range(4)]
+    crit = torch.nn.CrossEntropyLoss()
+    runs = []
+    for pipelined in (True, False):
+        torch.manual_seed(99)
+        model, _ = _build(config, seed=6)
+        model.train()
+        model.engine.calls = 0
+        opt = FusedAdamW(model, base_lr=4e-4, weight_decay=1e-2, warmup_steps=1, t_total=10, max_grad_norm=0.5)
+        opt.pipeline_update = pipelined
+        import inspect
+        assert inspect.signature(FusedAdamW.__init__).parameters["pipeline_update"].default is False  # opt-in
+        trace = []
+        for b in batches:
+            loss, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, "cuda", "TASK15", b, model, crit)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            trace.append((float(loss), opt.arena.param.clone(), opt.exp_avg.clone()))
+        assert (model.engine.chunk_events is not None) == pipelined
+        # an evaluation forward right behind a step sees the updated weights either way
+        model.eval()
+        with torch.no_grad():
+            b = tuple(t.cuda() for t in batches[0])
+            trace.append((0.0, model(b[3], b[0], b[1], "TASK15", b[6], b[5], b[2])[0].clone(), opt.exp_avg.clone()))
+        runs.append(trace)
+    for (l1, p1, m1), (l2, p2, m2) in zip(*runs):
+        assert l1 == l2 and torch.equal(p1, p2) and torch.equal(m1, m2)
+
+
 def test_unsupported_shapes_are_rejected_loudly():
     config = BertConfig.from_dict(uc2_cfg_dict(n_layers=1, vocab=100))
     model = BertForVLTasks(config, TASK_CFG, ["TASK15"]).cuda()
