@@ -395,11 +395,25 @@ def loc_linear_fwd(loc, w, b, y32, R, L, H):
 DETERMINISTIC_EMBED_BWD = True  # fixed-order reductions in the embedding backward (False: float atomics, arrival order)
 
 
+_WS_CACHE = {}  # persistent workspaces of the fixed-order reductions, keyed by (kind, device, stream, size): launches of one
+                # stream are ordered, so they can share one buffer -- no allocator traffic on the hot path
+
+
+def _ws(kind, device, nbytes):
+    key = (kind, str(device), _stream(), int(nbytes))
+    t = _WS_CACHE.get(key)
+    if t is None:
+        if len(_WS_CACHE) > 64:
+            _WS_CACHE.clear()
+        t = _WS_CACHE[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    return t
+
+
 def loc_linear_bwd(loc, dy32, dw, db, R, L, H, deterministic=None):
     """dw [H, L], db [H] += ...; deterministic: row blocks summed in a fixed order through a workspace (default), else
     float atomics."""
     det = DETERMINISTIC_EMBED_BWD if deterministic is None else deterministic
-    ws = _tmp(torch.empty(_lib.lib().vl_loc_bwd_ws_floats(R, H), dtype=torch.float32, device=dy32.device)) if det else None
+    ws = _ws("loc", dy32.device, 4 * _lib.lib().vl_loc_bwd_ws_floats(R, H)) if det else None
     _lib.check(_lib.lib().vl_loc_linear_bwd(_p(loc), _p(dy32), _p(dw), _p(db), R, L, H, _p(ws), _stream()),
                "vl_loc_linear_bwd")
 
@@ -415,7 +429,7 @@ def scatter_add_det(tables, dz32, R, H):
         arr[6 * i:6 * i + 6] = [_p(ids), kind, _p(table), skip, 0 if flags is None else _p(flags), T]
     L = _lib.lib()
     nbytes = L.vl_scatter_det_ws_bytes(n, R, H)
-    ws = _tmp(torch.empty(nbytes, dtype=torch.uint8, device=dz32.device))
+    ws = _ws("scatter", dz32.device, nbytes)
     _lib.check(L.vl_scatter_add_det(ctypes.cast(arr, ctypes.c_void_p), n, _p(dz32), R, H, _p(ws), nbytes, _stream()),
                "vl_scatter_add_det")
 
