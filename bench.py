@@ -450,7 +450,10 @@ def main():
                 roof["fused_attention"] = dict(
                     op="vl_qkv_attention_fwd (QKV projection 3-pass bf16 + attention core, 2 launches sharing split-bf16 Q|K|V)",
                     achieved=round(aq, 2), frac=round(aq / MFMA_BF16_PEAK_TFLOPS, 4), target_frac=0.70,
-                    ceiling_frac_3pass=round(1.0 / 3.0, 4), mfma_issue_frac=round(3 * aq / MFMA_BF16_PEAK_TFLOPS, 4),
+                    ceiling_frac_3pass=round(1.0 / 3.0, 4), frac_of_ceiling=round(3 * aq / MFMA_BF16_PEAK_TFLOPS, 4),
+                    ceiling_note="the 1e-3 logit contract needs 3 MFMA passes per algorithmic MAC in the projection (no 2-pass "
+                                 "scheme fits: tests/precision_study.py), so the op's algorithmic ceiling is 1/3 of the peak",
+                    mfma_issue_frac=round(3 * aq / MFMA_BF16_PEAK_TFLOPS, 4),
                     launches=q["launches"], avg_us=round(1e3 * q["ms"] / q["launches"], 2),
                     algorithmic_gflop_per_launch=round(q["flops"] / q["launches"] / 1e9, 2))
             if 1 in gs:
