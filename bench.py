@@ -271,6 +271,8 @@ def main():
         model.engine.stack.dx_tile = int(os.environ["BENCH_DX_TILE"])
     if os.environ.get("BENCH_DW_BUDGET"):  # A/B: stream-K weight-gradient GEMMs on this many workgroups (0 = a workgroup per tile)
         model.engine.stack.dw_budget = int(os.environ["BENCH_DW_BUDGET"])
+    if os.environ.get("BENCH_DW_TAIL_BUDGET"):  # A/B: stream-K form (this many workgroups) for the last dW launch of backward
+        model.engine.stack.dw_tail_budget = int(os.environ["BENCH_DW_TAIL_BUDGET"])
     if os.environ.get("BENCH_GEMM_PERSIST"):  # A/B: persistent ping-pong GEMM, "fwd,bwd" workgroup counts (0 = tile per workgroup)
         model.engine.stack.gemm_persist = tuple(int(x) for x in os.environ["BENCH_GEMM_PERSIST"].split(","))
     if os.environ.get("BENCH_NONDET_EMBED", "0") == "1":  # A/B: float atomics in the embedding backward (arrival order)

@@ -325,7 +325,8 @@ extern "C" int vl_stack_bwd(const int64_t* d, int64_t layer_hi, int64_t layer_lo
           a_2, H, bh, I, y[VL_LY_GRAD0 + 12], I, y[VL_LY_MASK0 + 5], H, I, 0};
       // (VL_ST_DW_BUDGET > 0: the stream-K form on a fixed number of workgroups -- the dX products of the main stream
       // keep the other CUs; launches of the side stream share the workspace in stream order)
-      const int64_t budget = d[VL_ST_DW_BUDGET];
+      // (the last layer of backward has the chip to itself once the main stream has run dry: VL_ST_DW_TAIL_BUDGET)
+      const int64_t budget = (l == 0 && d[VL_ST_DW_TAIL_BUDGET] > 0) ? d[VL_ST_DW_TAIL_BUDGET] : d[VL_ST_DW_BUDGET];
       void* skws = ptr<void>(d[VL_ST_DW_SK_WS]);
       auto dw = [&](const int64_t* probs, int64_t n, int64_t rows) {
         if (budget > 0 && rows >= 1024)

@@ -315,6 +315,9 @@ class LayerStack(object):
         # of the main stream keep the remaining CUs (88 + 168 one-round dX products at c2); 0 = one workgroup per 256 x 256
         # tile (108 per layer at c2)
         self.dw_budget = 0
+        # ... of the last weight-gradient launch of backward alone (layer 0: the main stream has nothing left to run beside
+        # it, so it may take the whole chip: 216 workgroups = every tile cut in two)
+        self.dw_tail_budget = 0
         # persistent form of the ping-pong GEMM (VL_GX_PERSIST): workgroup counts for (forward 3-pass, backward single-pass)
         # products; 0 = one workgroup per tile.  Measured at c2 (same box, profiles/r03_ab_log.txt): forward 16.09 -> 16.05
         # ms / step (bit-identical results), backward neutral to negative beside the weight-gradient stream
@@ -465,14 +468,16 @@ class LayerStack(object):
         F_, LF_ = VL["VL_ST_FIELDS"], VL["VL_LY_FIELDS"]
         for l in range(len(self.specs)):
             d[F_ + l * LF_ + VL["VL_LY_EV_READY"]] = 0 if evs is None else evs[l].cuda_event
-        if ar.need_grad and self.dw_budget > 0:
-            if ar.dw_sk_ws is None or ar.dw_sk_budget != self.dw_budget:
-                ar.dw_sk_ws, ar.dw_sk_budget = ops.dw_streamk_ws(self.dw_budget, ar.x32.device), self.dw_budget
+        sk = max(int(self.dw_budget), int(self.dw_tail_budget))
+        if ar.need_grad and sk > 0:
+            if ar.dw_sk_ws is None or ar.dw_sk_budget != sk:
+                ar.dw_sk_ws, ar.dw_sk_budget = ops.dw_streamk_ws(sk, ar.x32.device), sk
             d[VL["VL_ST_DW_BUDGET"]] = int(self.dw_budget)
+            d[VL["VL_ST_DW_TAIL_BUDGET"]] = int(self.dw_tail_budget)
             d[VL["VL_ST_DW_SK_WS"]] = ar.dw_sk_ws.data_ptr()
             d[VL["VL_ST_DW_SK_WS_BYTES"]] = ar.dw_sk_ws.numel()
         else:
-            d[VL["VL_ST_DW_BUDGET"]] = 0
+            d[VL["VL_ST_DW_BUDGET"]] = d[VL["VL_ST_DW_TAIL_BUDGET"]] = 0
         side_ptr = None
         if ar.need_grad and self.overlap_dw:
             dev = ar.x32.device

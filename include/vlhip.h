@@ -246,7 +246,7 @@ int vl_ln_bwd_reduce2(const float* ws_a, int64_t M_a, float* dgamma_a, float* db
  * descending order: the critical path on stream_main, the optimizer-only work (K-major re-layout, column sums, grouped
  * weight-gradient GEMM) forked per layer onto stream_side (NULL = everything on stream_main); the caller joins them.
  * ------------------------------------------------------------------------------------------------------------ */
-#define VL_ST_MAGIC_VALUE 0x564c5354414b33ll
+#define VL_ST_MAGIC_VALUE 0x564c5354414b34ll
 enum {
   VL_ST_MAGIC = 0,
   VL_ST_B = 1,
@@ -294,7 +294,10 @@ enum {
   VL_ST_DW_SK_WS_BYTES = 38,
   VL_ST_GEMM_PERSIST = 39, /* VL_GX_PERSIST of the stack's GEMMs: low 16 bits for the 3-pass products of forward, next 16 for the
                               single-pass products of backward (0 = one workgroup per tile) */
-  VL_ST_FIELDS = 40
+  VL_ST_DW_TAIL_BUDGET = 40, /* > 0: the weight-gradient GEMM of the LAST layer vl_stack_bwd runs (layer 0: nothing is left on the
+                                main stream to share the chip with) takes the stream-K form on this many workgroups (needs
+                                VL_ST_DW_SK_WS sized for it) */
+  VL_ST_FIELDS = 48
 };
 enum {
   VL_LY_X32 = 0,

@@ -639,7 +639,7 @@ def test_attention2_forward_backward(B, T, V):
     assert rel <= 2e-2 and err <= 3e-2 * g.abs().max().item()  # P / dS are rounded to bf16 inside (2^-9 relative each)
 
 
-@pytest.mark.parametrize("B,S", [(3, 56), (2, 120), (1, 10)])
+@pytest.mark.parametrize("B,S", [(3, 56), (2, 120), (1, 10), (2, 140), (1, 156)])  # (4 / 8 / 9 / 10 key-tile instances)
 def test_attention2_head_dim_32(B, S):
     """head dim 32 (the tiny c1 config: hidden 128, 4 heads)."""
     nh, dh = 4, 32
