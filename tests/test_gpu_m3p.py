@@ -141,16 +141,15 @@ def test_gradient_exchange_during_backward_is_bit_identical_to_the_plain_path(m3
         torch.cuda.synchronize()
         acc.append(opt.arena.grad.clone())
         opt.zero_grad()
-        # (compared before any optimizer step: Adam turns the last-bit noise of the float atomics into +-lr on the
-        # parameters whose gradient is tiny, after which the two trajectories are no longer comparable element-wise)
+        # (round 3: the embedding scatter-adds, the box-location Linear and the clip norm reduce in a fixed order, so the two
+        # gradient routes are bit-identical -- also through three optimizer steps)
         for _ in range(3):
             loss, _ = task_utils.ForwardModelsTrain(config, TASK_CFG, "cuda", "TASK15", batch, model, crit)
             loss.backward()
             opt.step()
         losses.append(float(loss))
-    # same kernels, same data: equal up to the order of the float atomics in the embedding scatter-adds
-    scale = grads[0].abs().max().item()
-    assert (grads[0] - grads[1]).abs().max().item() <= 1e-5 * scale
-    assert abs(losses[0] - losses[1]) <= 1e-3 * abs(losses[0])
-    assert (acc[0] - acc[1]).abs().max().item() <= 1e-5 * acc[0].abs().max().item()
-    assert (acc[0] - 2 * grads[0]).abs().max().item() <= 1e-5 * acc[0].abs().max().item()
+    # same kernels, same data, fixed summation orders: bit-identical
+    assert torch.equal(grads[0], grads[1]), int((grads[0] != grads[1]).sum())
+    assert losses[0] == losses[1]
+    assert torch.equal(acc[0], acc[1])
+    assert torch.equal(acc[0], 2 * grads[0])
