@@ -98,18 +98,24 @@ __device__ __forceinline__ void image_store(const GemmArgs& p, int m, int n0, co
 // lcol (may be NULL) / lpitch: LDS staging of the K-major image (ping-pong kernel): element t goes to lcol[t * lpitch];
 // without it the image is written by 2-byte global stores (correct on every kernel, slow: 32-byte segments)
 template <int EPI>
+// has_bq / bq0 (bq1): the bias of these columns, preloaded by the caller (the ping-pong kernel fetches a wave's bias values once
+// per M half instead of once per 16-row tile: a dependent load per store group otherwise)
 __device__ __forceinline__ void epilogue_store4(const GemmArgs& p, float* out32, int m, int n0, f32x4 v, bool want_cs,
-                                                float (&csum)[4], bf16_raw* lcol = nullptr, int lpitch = 0) {
+                                                float (&csum)[4], bf16_raw* lcol = nullptr, int lpitch = 0,
+                                                bool has_bq = false, float4 bq0 = float4{0.f, 0.f, 0.f, 0.f},
+                                                bool has_rq = false, float4 rq = float4{0.f, 0.f, 0.f, 0.f}) {
   const bool vec = p.vec && (n0 + 3 < p.N);
   if (vec) {
     if (p.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(p.bias + n0);
+      const float4 b = has_bq ? bq0 : *reinterpret_cast<const float4*>(p.bias + n0);
       v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
     }
     if (EPI == VL_EPI_F32) {
       const long o = (long)m * p.ldc + n0;
       if (p.resid) {
-        const float4 r = *reinterpret_cast<const float4*>(p.resid + o);
+        // (has_rq: preloaded by the caller -- the residual may alias nothing, but the compiler cannot know: without the
+        // preload every group's load waits behind the previous group's store)
+        const float4 r = has_rq ? rq : *reinterpret_cast<const float4*>(p.resid + o);
         v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
       }
       VL_EXP_ST *reinterpret_cast<float4*>(out32 + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -209,16 +215,19 @@ __device__ __forceinline__ uint4 pack8(const ushort4& a, const ushort4& b) {
 template <int EPI>
 __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32, int m, int n0, f32x4 v0, f32x4 v1,
                                                 bool want_cs, float (&c0)[4], float (&c1)[4], bf16_raw* lcol = nullptr,
-                                                int lpitch = 0) {
+                                                int lpitch = 0, bool has_bq = false, float4 bq0 = float4{0.f, 0.f, 0.f, 0.f},
+                                                float4 bq1 = float4{0.f, 0.f, 0.f, 0.f}, bool has_uq = false,
+                                                uint4 uq = uint4{0u, 0u, 0u, 0u}) {
   if (!(p.vec8 && n0 + 7 < p.N)) {
-    epilogue_store4<EPI>(p, out32, m, n0, v0, want_cs, c0, lcol, lpitch);
-    if (n0 + 4 < p.N) epilogue_store4<EPI>(p, out32, m, n0 + 4, v1, want_cs, c1, lcol ? lcol + 4 * lpitch : nullptr, lpitch);
+    epilogue_store4<EPI>(p, out32, m, n0, v0, want_cs, c0, lcol, lpitch, has_bq, bq0);
+    if (n0 + 4 < p.N)
+      epilogue_store4<EPI>(p, out32, m, n0 + 4, v1, want_cs, c1, lcol ? lcol + 4 * lpitch : nullptr, lpitch, has_bq, bq1);
     return;
   }
   float x[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
   if (p.bias) {
-    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + n0);
-    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + n0 + 4);
+    const float4 b0 = has_bq ? bq0 : *reinterpret_cast<const float4*>(p.bias + n0);
+    const float4 b1 = has_bq ? bq1 : *reinterpret_cast<const float4*>(p.bias + n0 + 4);
     x[0] += b0.x; x[1] += b0.y; x[2] += b0.z; x[3] += b0.w; x[4] += b1.x; x[5] += b1.y; x[6] += b1.z; x[7] += b1.w;
   }
   const long o = (long)m * p.ld16 + n0;
@@ -238,7 +247,7 @@ __device__ __forceinline__ void epilogue_store8(const GemmArgs& p, float* out32,
     VL_EXP_ST *reinterpret_cast<uint4*>(p.out_hi + o) = pack8(h0, h1);
     VL_EXP_ST *reinterpret_cast<uint4*>(p.out_lo + o) = pack8(l0, l1);
   } else if (EPI == VL_EPI_DGELU_BF16) {
-    const uint4 uu = *reinterpret_cast<const uint4*>(p.aux16 + o);
+    const uint4 uu = has_uq ? uq : *reinterpret_cast<const uint4*>(p.aux16 + o);  // (preloaded: see epilogue_store4's residual)
     const unsigned w[4] = {uu.x, uu.y, uu.z, uu.w};
     bf16_raw r[8];
 #pragma unroll
@@ -818,6 +827,46 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int t = 0; t < 4; ++t) csum[qn][j][t] = 0.f;
+    // this lane's bias values: they depend on the column group only -- fetched once here, not once per 16-row tile
+    float4 bpre[2][NJ + 1];
+    const bool use_bpre = p.bias != nullptr && p.vec;
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int cb = e_col0 + qn * BH + wc * (NJ * 16);
+        const int n0 = j < NJP ? cb + 32 * (j >> 1) + 8 * (lane_e >> 4) + 4 * (j & 1) : cb + j * 16 + 4 * (lane_e >> 4);
+        bpre[qn][j] = (use_bpre && n0 + 3 < p.N) ? *reinterpret_cast<const float4*>(p.bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j == NJ - 1) bpre[qn][NJ] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    // the residual (fp32 epilogue) / the saved GELU' (its backward epilogue) of this half: all loads go out before the first
+    // store, instead of one load -> use -> store chain per group
+    constexpr bool PRE_R = EPI == VL_EPI_F32, PRE_U = EPI == VL_EPI_DGELU_BF16;
+    float4 rpre[PRE_R ? MI : 1][2][PRE_R ? NJ : 1];
+    uint4 upre[PRE_U ? MI : 1][2][PRE_U ? (NJ + 1) / 2 : 1];
+    const bool use_rpre = PRE_R && p.resid != nullptr && p.vec;
+    const bool use_upre = PRE_U && p.vec8 && NJP == NJ;
+    if (PRE_R || PRE_U) {
+#pragma unroll
+      for (int i = 0; i < (qm == 0 ? MI : MI1); ++i) {
+        const int m = e_row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane_e & 15);
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const int cb = e_col0 + qn * BH + wc * (NJ * 16);
+            if (PRE_R) {
+              const int n0 = cb + j * 16 + 4 * (lane_e >> 4);
+              rpre[PRE_R ? i : 0][qn][PRE_R ? j : 0] = (use_rpre && m < p.M && n0 + 3 < p.N)
+                  ? *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldc + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else if ((j & 1) == 0) {
+              const int n0 = cb + 32 * (j >> 1) + 8 * (lane_e >> 4);
+              upre[PRE_U ? i : 0][qn][PRE_U ? j / 2 : 0] = (use_upre && m < p.M && n0 + 7 < p.N)
+                  ? *reinterpret_cast<const uint4*>(p.aux16 + (long)m * p.ld16 + n0) : make_uint4(0u, 0u, 0u, 0u);
+            }
+          }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < (qm == 0 ? MI : MI1); ++i) {
       const int m = e_row0 + qm * AH + wr * ((qm == 0 ? MI : MI1) * 16) + i * 16 + (lane_e & 15);
@@ -835,14 +884,16 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
               if (row_ok && n0 < p.N)
                 epilogue_store8<EPI>(p, out32, m, n0, acc[qm][qn][i][j], acc[qm][qn][i][j + 1 < NJ ? j + 1 : j], want_cs,
                                      csum[qn][j], csum[qn][j + 1 < NJ ? j + 1 : j],
-                                     lrow ? lrow + (qn * NJ * 16 + nl) * IMG_LP : nullptr, IMG_LP);
+                                     lrow ? lrow + (qn * NJ * 16 + nl) * IMG_LP : nullptr, IMG_LP, use_bpre, bpre[qn][j],
+                                     bpre[qn][j + 1], use_upre, upre[PRE_U ? i : 0][qn][PRE_U ? j / 2 : 0]);
             }
           } else {
             const int nl = j * 16 + 4 * (lane_e >> 4);
             const int n0 = cb + nl;
             if (row_ok && n0 < p.N)
               epilogue_store4<EPI>(p, out32, m, n0, acc[qm][qn][i][j], want_cs, csum[qn][j],
-                                   lrow ? lrow + (qn * NJ * 16 + nl) * IMG_LP : nullptr, IMG_LP);
+                                   lrow ? lrow + (qn * NJ * 16 + nl) * IMG_LP : nullptr, IMG_LP, use_bpre, bpre[qn][j],
+                                   use_rpre, rpre[PRE_R ? i : 0][qn][PRE_R ? j : 0]);
           }
         }
     }
