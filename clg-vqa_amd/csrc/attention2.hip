@@ -109,17 +109,36 @@ __device__ __forceinline__ float keep_of(const Attn2Args& p, unsigned bits, int 
   return u >= p.thr16 ? p.inv_keep : 0.0f;
 }
 
-// stage rows [0, Spad) x DH bf16 of one matrix into an LDS tile (zeros beyond `rows`); src row pitch ld elements
-template <int DH, int NTHR>
-__device__ __forceinline__ void stage16(unsigned char* dst, const bf16_raw* src, long ld, int rows, int Spad, int tid) {
-  constexpr int CH = DH / 8;  // 16-byte chunks per row
-  for (int idx = tid; idx < Spad * CH; idx += NTHR) {
-    const int row = idx / CH, c = idx - row * CH;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (row < rows) v = *reinterpret_cast<const uint4*>(src + (long)row * ld + c * 8);
-    *reinterpret_cast<uint4*>(dst + Geo<DH>::chunk_off(row, c)) = v;
+// stage rows [0, SPAD) x DH bf16 of NM matrices into their LDS tiles (zeros beyond rows[m]); src row pitch ld[m] elements.
+// ALL loads of all matrices are issued before the first LDS store: written as a loop of "if (row < rows) load; store" the
+// compiler emitted load -> s_waitcnt vmcnt(0) -> ds_write per chunk, i.e. 8 - 20 memory round trips one after the other at
+// the head of every workgroup.  Loads are unconditional (row clamped to 0, value replaced by zeros afterwards) so that the
+// whole batch is one basic block.
+template <int DH, int NTHR, int SPAD, int NM> struct StageBatch {
+  static constexpr int CH = DH / 8, TOT = SPAD * CH, IT = (TOT + NTHR - 1) / NTHR;
+  static constexpr bool EXACT = TOT % NTHR == 0;
+  uint4 v[NM][IT];
+  __device__ __forceinline__ void load(const bf16_raw* const (&src)[NM], const long (&ld)[NM], const int (&rows)[NM], int tid) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTHR, row = idx / CH, c = idx - row * CH;
+        const bool ok = row < rows[m];  // (idx >= TOT -> row >= SPAD >= rows)
+        v[m][i] = *reinterpret_cast<const uint4*>(src[m] + (long)(ok ? row : 0) * ld[m] + c * 8);
+      }
   }
-}
+  __device__ __forceinline__ void store(unsigned char* const (&dst)[NM], const int (&rows)[NM], int tid) const {
+#pragma unroll
+    for (int m = 0; m < NM; ++m)
+#pragma unroll
+      for (int i = 0; i < IT; ++i) {
+        const int idx = tid + i * NTHR, row = idx / CH, c = idx - row * CH;
+        if (EXACT || idx < TOT)
+          *reinterpret_cast<uint4*>(dst[m] + Geo<DH>::chunk_off(row, c)) = row < rows[m] ? v[m][i] : make_uint4(0u, 0u, 0u, 0u);
+      }
+  }
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward
@@ -155,35 +174,42 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_k
   unsigned char* sVh = sKl + Spad * PITCH;
   unsigned char* sVl = sVh + Spad * PITCH;
   float* smask = reinterpret_cast<float*>(sVl + Spad * PITCH);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / p.nh, h = blockIdx.x - b * p.nh;
   const int S = p.S;
   const long ld = 3L * p.H;
   const bf16_raw* bh = p.qkv_hi + (long)b * S * ld + h * DH;
   const bf16_raw* bl = p.qkv_lo + (long)b * S * ld + h * DH;
-  stage16<DH, NW * 64>(sKh, bh + p.H, ld, S, Spad, tid);
-  stage16<DH, NW * 64>(sKl, bl + p.H, ld, S, Spad, tid);
-  stage16<DH, NW * 64>(sVh, bh + 2 * p.H, ld, S, Spad, tid);
-  stage16<DH, NW * 64>(sVl, bl + 2 * p.H, ld, S, Spad, tid);
-  for (int k = tid; k < Spad; k += NW * 64) smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
   const int l15 = lane & 15, g = lane >> 4, qq = l15 >> 2, pp = lane & 3;
   const int nqt = (p.nq + 15) >> 4;
-  __syncthreads();
-
-  for (int qt = wave; qt < nqt; qt += NW) {
-    const int q = qt * 16 + l15;
-    // this lane's query row as the B operand of S^T = K.Q^T: Q[q][32 ks + 8 g ..]
-    bf16x8 qh[KS], ql[KS];
+  // everything this workgroup reads before its first product is in flight at once: key mask, K / V (hi, lo), and the first
+  // query tile's rows (B operand of S^T = K.Q^T: Q[q][32 ks + 8 g ..], straight into registers)
+  const float mask_v = p.addmask[(long)b * S + (tid < S ? tid : 0)];
+  StageBatch<DH, NW * 64, Spad, 4> st;
+  const bf16_raw* const srcs[4] = {bh + p.H, bl + p.H, bh + 2 * p.H, bl + 2 * p.H};
+  unsigned char* const dsts[4] = {sKh, sKl, sVh, sVl};
+  const long lds4[4] = {ld, ld, ld, ld};
+  const int rows4[4] = {S, S, S, S};
+  st.load(srcs, lds4, rows4, tid);
+  bf16x8 qh[KS], ql[KS];
+  auto load_q = [&](int qt) {
+    const int q = qt * 16 + l15, qr = q < S ? q : 0;  // (rows past S: any finite values, their results are never stored)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      uint4 vh = make_uint4(0u, 0u, 0u, 0u), vl = vh;
-      if (q < S) {
-        vh = *reinterpret_cast<const uint4*>(bh + (long)q * ld + 32 * ks + 8 * g);
-        vl = *reinterpret_cast<const uint4*>(bl + (long)q * ld + 32 * ks + 8 * g);
-      }
-      qh[ks] = __builtin_bit_cast(bf16x8, vh);
-      ql[ks] = __builtin_bit_cast(bf16x8, vl);
+      qh[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bh + (long)qr * ld + 32 * ks + 8 * g));
+      ql[ks] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bl + (long)qr * ld + 32 * ks + 8 * g));
     }
+  };
+  // query tiles go to waves round-robin from a per-workgroup start: when NT is not a multiple of NW (9 tiles on 8 waves) the
+  // wave with one tile more is a different one -- on a different SIMD -- in the workgroups that share a CU
+  const int w0 = NT % NW == 0 ? wave : (wave + (int)((blockIdx.x * 0x9E3779B1u) >> 16)) & (NW - 1);
+  if (w0 < nqt) load_q(w0);
+  if (tid < Spad) smask[tid] = tid < S ? mask_v : -INFINITY;
+  st.store(dsts, rows4, tid);
+  __syncthreads();
+
+  for (int qt = w0; qt < nqt; qt += NW) {
+    const int q = qt * 16 + l15;
     f32x4 sc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -198,6 +224,9 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_k
       }
       asm volatile("" ::: "memory");  // keep the next tile's LDS reads here: hoisting all NT tiles' fragments costs ~100 VGPRs
     }
+    // the wave's next query tile arrives under the softmax and P.V of this one (9 key tiles: no registers to spare under the
+    // 128-VGPR budget of two 8-wave workgroups per CU; loaded at the end of the trip instead)
+    if (NT != 9 && qt + NW < nqt) load_q(qt + NW);
     // softmax over the keys of query q: this lane holds keys 16 t + 4 g + r
     float m = -INFINITY;
 #pragma unroll
@@ -272,6 +301,7 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_k
         *reinterpret_cast<ushort4*>(p.ctx_lo + off) = lo;
       }
     }
+    if (NT == 9 && qt + NW < nqt) load_q(qt + NW);
   }
 }
 
@@ -293,29 +323,41 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_BWD_MINW(NT, NW)) void attn2_bwd_k
   float* smask = reinterpret_cast<float*>(sO + Spad * PITCH);
   float* slse = smask + Spad;
   float* sdelta = slse + Spad;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.x / p.nh, h = blockIdx.x - b * p.nh;
   const int S = p.S;
   const long ld = 3L * p.H;
   const bf16_raw* bh = p.qkv_hi + (long)b * S * ld + h * DH;
-  stage16<DH, NW * 64>(sQ, bh, ld, S, Spad, tid);
-  stage16<DH, NW * 64>(sK, bh + p.H, ld, S, Spad, tid);
-  stage16<DH, NW * 64>(sV, bh + 2 * p.H, ld, S, Spad, tid);
-  stage16<DH, NW * 64>(sO, p.dctx + (long)b * p.ctx_rows * p.H + h * DH, p.H, p.nq, Spad, tid);
-  for (int k = tid; k < Spad; k += NW * 64) {
-    smask[k] = k < S ? p.addmask[(long)b * S + k] : -INFINITY;
-    slse[k] = k < S ? p.lse[((long)b * p.nh + h) * S + k] : INFINITY;  // +inf -> P = 0 for padded queries
-    sdelta[k] = 0.f;
-  }
   const int l15 = lane & 15, g = lane >> 4, qq = l15 >> 2, pp = lane & 3;
   const int nqt = (p.nq + 15) >> 4;      // query tiles that carry a gradient
   const int nqt_all = (S + 15) >> 4;
   const unsigned row0 = (unsigned)((b * p.nh + h) * S);
   bf16_raw* dq_base = p.dqkv + (long)b * S * ld + h * DH;
+  // all of the workgroup's input in flight at once (see StageBatch)
+  const int kc = tid < S ? tid : 0;
+  const float mask_v = p.addmask[(long)b * S + kc];
+  const float lse_v = p.lse[((long)b * p.nh + h) * S + kc];
+  StageBatch<DH, NW * 64, Spad, 4> st;
+  const bf16_raw* const srcs[4] = {bh, bh + p.H, bh + 2 * p.H, p.dctx + (long)b * p.ctx_rows * p.H + h * DH};
+  unsigned char* const dsts[4] = {sQ, sK, sV, sO};
+  const long lds4[4] = {ld, ld, ld, (long)p.H};
+  const int rows4[4] = {S, S, S, p.nq};
+  st.load(srcs, lds4, rows4, tid);
+  if (tid < Spad) {
+    smask[tid] = tid < S ? mask_v : -INFINITY;
+    slse[tid] = tid < S ? lse_v : INFINITY;  // +inf -> P = 0 for padded queries
+    sdelta[tid] = 0.f;
+  }
+  st.store(dsts, rows4, tid);
   __syncthreads();
+  // tiles go to waves round-robin from a per-workgroup start, phase B half a turn after phase A: with 9 tiles on 4 waves the
+  // third tile of the two phases lands on different waves (5 tile times per workgroup instead of 6), and on different SIMDs
+  // in the workgroups that share a CU
+  const int wA = NT % NW == 0 ? wave : (wave + (int)((blockIdx.x * 0x9E3779B1u) >> 16)) & (NW - 1);
+  const int wB = NT % NW == 0 ? wave : (wA + NW / 2) & (NW - 1);
 
   // ---- phase A: delta and dQ (transposed layout: lane = one query, keys 16 t + 4 g + r) ------------------------
-  for (int qt = wave; qt < nqt_all; qt += NW) {
+  for (int qt = wA; qt < nqt_all; qt += NW) {
     const int q = qt * 16 + l15;
     if (qt >= nqt) {  // rows without a gradient: dQ = 0
       if (q < S) {
@@ -397,7 +439,7 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_BWD_MINW(NT, NW)) void attn2_bwd_k
 
   // ---- phase B: dK and dV (plain layout: lane = one key, queries 16 qt + 4 g + r) ------------------------------
   const int nqp = (nqt + 1) >> 1;  // query-tile pairs
-  for (int kt = wave; kt < NT; kt += NW) {
+  for (int kt = wB; kt < NT; kt += NW) {
     const int key = kt * 16 + l15;
     bf16x8 fk[KS], fv[KS];
 #pragma unroll
