@@ -35,6 +35,14 @@
 
 namespace {
 
+// timing experiments with WRONG RESULTS (variant builds only, tools/attn_exp.sh): -DVL_EXP_ATTN=<bits> takes out of the forward
+// kernel 1 = the input loads, 2 = everything between staging and the output stores, 4 = the output stores
+#ifdef VL_EXP_ATTN
+#define VL_EXP_OFF(bit) (((VL_EXP_ATTN) & (bit)) && p.S != -1)
+#else
+#define VL_EXP_OFF(bit) false
+#endif
+
 // head dim DH (64: the model configs; 32: the tiny "c1" plumbing config) is a template parameter: KS = DH / 32 k-steps
 // per Q.K^T product, DT = DH / 16 output column tiles, LDS row pitch DH * 2 + 16 bytes
 template <int DH> struct Geo {
@@ -94,6 +102,40 @@ __device__ __forceinline__ void pack8_split(const float* x, bf16x8& hi, bf16x8& 
   }
   hi = __builtin_bit_cast(bf16x8, h);
   lo = __builtin_bit_cast(bf16x8, l);
+}
+
+// Output rows as 16-byte stores.  The MFMA result layout leaves a lane (row = lane & 15, g = lane >> 4) with columns 16 dt +
+// 4 g .. + 3 of its row for every column tile dt: written as they lie that is an 8-byte store per tile, 32-byte pieces of
+// 16 different rows per instruction, every 128-byte line of the output assembled from four partial writes (measured:
+// the forward kernel's 44 MB of stores alone took 22 us).  v_permlane16_swap_b32 exchanges, between the lane pairs
+// (g, g ^ 1), the halves they need from each other: after it a lane holds 8 consecutive columns 32 m + 4 g + 12 (g & 1)
+// of tile pair m -- one 16-byte store, 64-byte pieces per row, half the store instructions.  All 64 lanes must be active.
+__device__ __forceinline__ uint4 pair_cols(uint2 a, uint2 b) {  // a: tile 2m, b: tile 2m + 1 (4 bf16 each)
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+  const u32x2 x = __builtin_amdgcn_permlane16_swap(a.x, b.x, false, false);
+  const u32x2 y = __builtin_amdgcn_permlane16_swap(a.y, b.y, false, false);
+  return make_uint4(x[0], y[0], x[1], y[1]);
+}
+__device__ __forceinline__ int pair_col0(int m, int g) { return 32 * m + 4 * g + 12 * (g & 1); }
+__device__ __forceinline__ uint2 pack4(const f32x4& v) {
+  return make_uint2((unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16),
+                    (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16));
+}
+__device__ __forceinline__ void pack4_split(const f32x4& v, uint2& hi, uint2& lo) {
+  bf16_raw h[4], l[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) split_bf16(v[r], h[r], l[r]);
+  hi = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+  lo = make_uint2((unsigned)l[0] | ((unsigned)l[1] << 16), (unsigned)l[2] | ((unsigned)l[3] << 16));
+}
+// one row of DT column tiles (fp32 accumulators) -> bf16 at `row` (pointer to column 0 of this lane's row); `ok`: store
+template <int DT>
+__device__ __forceinline__ void store_row_bf16(bf16_raw* row, const f32x4 (&o)[DT], int g, bool ok) {
+#pragma unroll
+  for (int m = 0; m < DT / 2; ++m) {
+    const uint4 v = pair_cols(pack4(o[2 * m]), pack4(o[2 * m + 1]));
+    if (ok) *reinterpret_cast<uint4*>(row + pair_col0(m, g)) = v;
+  }
 }
 
 // 32 random bits per (row, key pair): two 16-bit uniform draws (low half = even key, high half = odd key)
@@ -190,8 +232,15 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_k
   unsigned char* const dsts[4] = {sKh, sKl, sVh, sVl};
   const long lds4[4] = {ld, ld, ld, ld};
   const int rows4[4] = {S, S, S, S};
-  st.load(srcs, lds4, rows4, tid);
+#ifdef VL_EXP_ATTN
+  for (int m = 0; m < 4; ++m)
+    for (int i = 0; i < st.IT; ++i) st.v[m][i] = make_uint4(0u, 0u, 0u, 0u);
+#endif
+  if (!VL_EXP_OFF(1)) st.load(srcs, lds4, rows4, tid);
   bf16x8 qh[KS], ql[KS];
+#ifdef VL_EXP_ATTN
+  for (int ks = 0; ks < KS; ++ks) qh[ks] = ql[ks] = zero_frag();
+#endif
   auto load_q = [&](int qt) {
     const int q = qt * 16 + l15, qr = q < S ? q : 0;  // (rows past S: any finite values, their results are never stored)
 #pragma unroll
@@ -203,13 +252,17 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_k
   // query tiles go to waves round-robin from a per-workgroup start: when NT is not a multiple of NW (9 tiles on 8 waves) the
   // wave with one tile more is a different one -- on a different SIMD -- in the workgroups that share a CU
   const int w0 = NT % NW == 0 ? wave : (wave + (int)((blockIdx.x * 0x9E3779B1u) >> 16)) & (NW - 1);
-  if (w0 < nqt) load_q(w0);
+  if (w0 < nqt && !VL_EXP_OFF(1)) load_q(w0);
   if (tid < Spad) smask[tid] = tid < S ? mask_v : -INFINITY;
   st.store(dsts, rows4, tid);
   __syncthreads();
 
   for (int qt = w0; qt < nqt; qt += NW) {
     const int q = qt * 16 + l15;
+    f32x4 o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!VL_EXP_OFF(2)) {
     f32x4 sc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -226,7 +279,7 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_k
     }
     // the wave's next query tile arrives under the softmax and P.V of this one (9 key tiles: no registers to spare under the
     // 128-VGPR budget of two 8-wave workgroups per CU; loaded at the end of the trip instead)
-    if (NT != 9 && qt + NW < nqt) load_q(qt + NW);
+    if (NT != 9 && qt + NW < nqt && !VL_EXP_OFF(1)) load_q(qt + NW);
     // softmax over the keys of query q: this lane holds keys 16 t + 4 g + r
     float m = -INFINITY;
 #pragma unroll
@@ -262,9 +315,6 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_k
       sc[t][0] *= inv * k0; sc[t][1] *= inv * k1; sc[t][2] *= inv * k2; sc[t][3] *= inv * k3;
     }
     // ctx^T[d][q] = sum_keys V^T[d][key] P^T[key][q]
-    f32x4 o[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int pr = 0; pr < NP; ++pr) {
       const int t0 = 2 * pr, t1 = 2 * pr + 1;
@@ -289,19 +339,23 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_FWD_MINW(NT, NW)) void attn2_fwd_k
       }
       asm volatile("" ::: "memory");
     }
-    if (q < p.nq) {
-      const long orow = (long)b * p.ctx_rows + q;
+    }  // (VL_EXP_OFF(2))
+    {
+      const bool ok = q < p.nq && !VL_EXP_OFF(4);
+      const long off = ((long)b * p.ctx_rows + (ok ? q : 0)) * p.H + h * DH;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        ushort4 hi, lo;
-        split_bf16(o[dt][0], hi.x, lo.x); split_bf16(o[dt][1], hi.y, lo.y);
-        split_bf16(o[dt][2], hi.z, lo.z); split_bf16(o[dt][3], hi.w, lo.w);
-        const long off = orow * p.H + h * DH + 16 * dt + 4 * g;
-        *reinterpret_cast<ushort4*>(p.ctx_hi + off) = hi;
-        *reinterpret_cast<ushort4*>(p.ctx_lo + off) = lo;
+      for (int m = 0; m < DT / 2; ++m) {
+        uint2 h0, l0, h1, l1;
+        pack4_split(o[2 * m], h0, l0);
+        pack4_split(o[2 * m + 1], h1, l1);
+        const uint4 vh = pair_cols(h0, h1), vl = pair_cols(l0, l1);
+        if (ok) {
+          *reinterpret_cast<uint4*>(p.ctx_hi + off + pair_col0(m, g)) = vh;
+          *reinterpret_cast<uint4*>(p.ctx_lo + off + pair_col0(m, g)) = vl;
+        }
       }
     }
-    if (NT == 9 && qt + NW < nqt) load_q(qt + NW);
+    if (NT == 9 && qt + NW < nqt && !VL_EXP_OFF(1)) load_q(qt + NW);
   }
 }
 
@@ -362,8 +416,8 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_BWD_MINW(NT, NW)) void attn2_bwd_k
     if (qt >= nqt) {  // rows without a gradient: dQ = 0
       if (q < S) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-          *reinterpret_cast<ushort4*>(dq_base + (long)q * ld + 16 * dt + 4 * g) = make_ushort4(0, 0, 0, 0);
+        for (int m = 0; m < DT / 2; ++m)
+          *reinterpret_cast<uint4*>(dq_base + (long)q * ld + pair_col0(m, g)) = make_uint4(0u, 0u, 0u, 0u);
       }
       continue;
     }
@@ -426,14 +480,7 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_BWD_MINW(NT, NW)) void attn2_bwd_k
         o[dt] = mfma(tr_frag2(sK + Geo<DH>::tr_off(kr0, dt, pp), sK + Geo<DH>::tr_off(kr1, dt, pp)), dsb, o[dt]);
       asm volatile("" ::: "memory");
     }
-    if (q < S) {
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        ushort4 v;
-        v.x = f32_to_bf16(o[dt][0]); v.y = f32_to_bf16(o[dt][1]); v.z = f32_to_bf16(o[dt][2]); v.w = f32_to_bf16(o[dt][3]);
-        *reinterpret_cast<ushort4*>(dq_base + (long)q * ld + 16 * dt + 4 * g) = v;
-      }
-    }
+    store_row_bf16<DT>(dq_base + (long)(q < S ? q : 0) * ld, o, g, q < S);
   }
   __syncthreads();  // sdelta complete
 
@@ -488,16 +535,10 @@ __global__ __launch_bounds__(NW * 64, VL_ATTN_BWD_MINW(NT, NW)) void attn2_bwd_k
         dK[dt] = mfma(tr_frag2(sQ + r0, sQ + r1), bds, dK[dt]);
       }
     }
-    if (key < S) {
-      bf16_raw* out = p.dqkv + ((long)b * S + key) * ld + h * DH;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        ushort4 a, c;
-        a.x = f32_to_bf16(dK[dt][0]); a.y = f32_to_bf16(dK[dt][1]); a.z = f32_to_bf16(dK[dt][2]); a.w = f32_to_bf16(dK[dt][3]);
-        c.x = f32_to_bf16(dV[dt][0]); c.y = f32_to_bf16(dV[dt][1]); c.z = f32_to_bf16(dV[dt][2]); c.w = f32_to_bf16(dV[dt][3]);
-        *reinterpret_cast<ushort4*>(out + p.H + 16 * dt + 4 * g) = a;
-        *reinterpret_cast<ushort4*>(out + 2 * p.H + 16 * dt + 4 * g) = c;
-      }
+    {
+      bf16_raw* out = p.dqkv + ((long)b * S + (key < S ? key : 0)) * ld + h * DH;
+      store_row_bf16<DT>(out + p.H, dK, g, key < S);
+      store_row_bf16<DT>(out + 2 * p.H, dV, g, key < S);
     }
   }
 }
