@@ -13,10 +13,13 @@
 //
 // One workgroup per (sample, head) -- 4 waves for S <= 80, 8 waves beyond (at S = 120 / 140 the LDS tiles allow two
 // workgroups per CU: 16 resident waves instead of 8 / 4 of round 2) -- with K and V (forward) / Q, K, V, dO (backward) in LDS as
-// [row][64] bf16 at a 128-byte pitch, the 16-byte chunks of a row XOR-swizzled with sw(row) = ((row >> 1) & 3) << 1 |
-// (row >> 3) & 1: conflict-free for the ds_read_b128 operand reads (16 consecutive rows, one chunk), for the transposing
-// ds_read_b64_tr_b16 reads (8 rows x one 32-byte block) and for the staging stores; round 2's padded 144-byte pitch measured
-// 0.36 - 0.38 SQ_LDS_BANK_CONFLICT per active LDS cycle (rows r and r + 7 of a transposing read overlap by 4 banks) and
+// [row][64] bf16 at a 128-byte pitch, the 16-byte chunks of a row XOR-swizzled with sw(row) = ((row >> 1) & 3) << 1.  The
+// swizzle is chosen by measurement (tools/lds_probe.hip: one kernel per access pattern under SQ_LDS_BANK_CONFLICT): of eight
+// candidates only this one and row & 7 are conflict-free for all three patterns -- the ds_read_b128 operand reads (16
+// consecutive rows, one chunk), the transposing ds_read_b64_tr_b16 reads (8 rows x one 32-byte block) and the staging
+// stores.  Round 3's first choice (the same | (row >> 3) & 1) was conflict-free on paper and measured 0.5 on the b128 reads
+// (0.22 / 0.28 for the whole kernels); gemm.hip's swizzles measure 0.5 on the transposing reads.  Round 2's padded 144-byte
+// pitch measured 0.36 - 0.38 SQ_LDS_BANK_CONFLICT per active LDS cycle and
 // cost 12 % more LDS.  Head dim 32 (the tiny c1 config) keeps a padded 80-byte pitch.  S <= 160: a query tile's whole key
 // range lives in registers (plain softmax).
 //
@@ -48,7 +51,7 @@ namespace {
 template <int DH> struct Geo {
   static constexpr int KS = DH / 32, DT = DH / 16, PITCH = DH == 64 ? 128 : DH * 2 + 16;
   // chunk swizzle of a row (16-byte chunks; 0 for the padded layout)
-  static __device__ __forceinline__ int sw(int row) { return DH == 64 ? ((((row >> 1) & 3) << 1) | ((row >> 3) & 1)) : 0; }
+  static __device__ __forceinline__ int sw(int row) { return DH == 64 ? (((row >> 1) & 3) << 1) : 0; }
   // byte offset of 16-byte chunk `chunk` of `row` (ds_read_b128 operand fragments, staging)
   static __device__ __forceinline__ int chunk_off(int row, int chunk) { return row * PITCH + ((chunk ^ sw(row)) << 4); }
   // byte offset of this lane's 8 bytes of a transposing read: columns 16 dt + 4 pp .. + 3 of `row`
