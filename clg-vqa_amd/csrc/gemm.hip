@@ -658,12 +658,24 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
   }
   // 1 pass: [0] / [1] are the two 32-deep k halves of the row; 3 passes: [0] = hi, [1] = lo of one 32-deep k step and
   // the products are issued product-major so that dependent accumulations are MI*NJ MFMAs apart
+  // (timing experiments, WRONG RESULTS, only meaningful together with VL_EXP_NO_DMA + VL_EXP_NO_READS: -DVL_EXP_NO_BARRIER drops the
+  // two barriers around every MFMA section, -DVL_EXP_NO_PRIO the priority flips)
+#ifdef VL_EXP_NO_BARRIER
+#define G3_BAR() do { } while (0)
+#else
+#define G3_BAR() __builtin_amdgcn_s_barrier()
+#endif
+#ifdef VL_EXP_NO_PRIO
+#define G3_PRIO(x) do { } while (0)
+#else
+#define G3_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 #define G3_MFMA(qm, qn, fb)                                                                                      \
   do {                                                                                                           \
-    __builtin_amdgcn_s_barrier();                                                                                \
+    G3_BAR();                                                                                                    \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
-    __builtin_amdgcn_s_setprio(1);                                                                               \
+    G3_PRIO(1);                                                                                                  \
     if (NSPLIT == 1) {                                                                                           \
       _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
       _Pragma("unroll") for (int i = 0; i < ((qm) == 0 ? MI : MI1); ++i)                                         \
@@ -680,9 +692,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmArgs p) {
       _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                             \
           acc[qm][qn][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][0], fa[i][0], acc[qm][qn][i][j], 0, 0, 0); \
     }                                                                                                            \
-    __builtin_amdgcn_s_setprio(0);                                                                               \
+    G3_PRIO(0);                                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                           \
-    __builtin_amdgcn_s_barrier();                                                                                \
+    G3_BAR();                                                                                                    \
   } while (0)
 
   // prologue: K-tile 0 complete, A0 / B0 of K-tile 1 in flight

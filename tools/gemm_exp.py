@@ -31,7 +31,13 @@ def med(fn, n=10):
 
 def main():
     g = torch.Generator().manual_seed(0)
-    mk = lambda r, c: (torch.randn(r, c, generator=g) * 0.1).to(DEV).to(BF16)  # noqa: E731
+    # GEMM_EXP_DATA=const: every operand element the same value (the matrix pipe's power draw depends on how many operand bits
+    # toggle: with constant operands the same instruction stream runs at a higher sustained clock); default: normal random
+    import os
+    if os.environ.get("GEMM_EXP_DATA", "random") == "const":
+        mk = lambda r, c: torch.full((r, c), 0.0625, device=DEV, dtype=BF16)  # noqa: E731
+    else:
+        mk = lambda r, c: (torch.randn(r, c, generator=g) * 0.1).to(DEV).to(BF16)  # noqa: E731
     xh, xl, hh, hl = mk(M, H), mk(M, H), mk(M, I), mk(M, I)
     wq, wql, w1, w1l, w2, w2l = mk(3 * H, H), mk(3 * H, H), mk(I, H), mk(I, H), mk(H, I), mk(H, I)
     b3, bI, bH = torch.zeros(3 * H, device=DEV), torch.zeros(I, device=DEV), torch.zeros(H, device=DEV)
