@@ -146,8 +146,10 @@ __device__ __forceinline__ unsigned hash32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
+// (ONE hash32 per key pair: the 64-bit seed is mixed on the host (splitmix64) into the additive / xor constants, the counter is
+// spread by the odd multiplier -- two rounds of hash32 per pair were 10 % of the S = 140 kernels' vector work)
 __device__ __forceinline__ unsigned drop_bits(const Attn2Args& p, unsigned row, unsigned pair, unsigned pairs_per_row) {
-  return hash32(hash32((row * pairs_per_row + pair) * 0x9E3779B1u + p.seed_lo) ^ p.seed_hi);
+  return hash32(((row * pairs_per_row + pair) * 0x9E3779B1u + p.seed_lo) ^ p.seed_hi);
 }
 __device__ __forceinline__ float keep_of(const Attn2Args& p, unsigned bits, int odd) {
   const unsigned u = odd ? (bits >> 16) : (bits & 0xFFFFu);
@@ -593,7 +595,9 @@ int fill_common(const char* fn, Attn2Args& a, int64_t B, int64_t S, int64_t nh, 
   VL_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "%s: dropout p must be in [0,1)", fn);
   a.B = (int)B; a.S = (int)S; a.nh = (int)nh; a.H = (int)(nh * dh); a.nq = (int)nq; a.ctx_rows = (int)nq;
   a.scale = 1.0f / sqrtf((float)dh); a.p_drop = p_drop; a.inv_keep = 1.0f / (1.0f - p_drop);
-  a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32) * 0x85ebca6bu + 0x27d4eb2fu;
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull;  // splitmix64: neighbouring seeds (layers, steps) -> unrelated constants
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+  a.seed_lo = (unsigned)z; a.seed_hi = (unsigned)(z >> 32);
   a.thr16 = (unsigned)(p_drop * 65536.0f + 0.5f);
   return 0;
 }

@@ -769,6 +769,48 @@ def test_attention2_dropout_is_consistent_between_forward_and_backward():
     assert abs(fd - an) <= 3e-2 * max(1.0, abs(fd)), (fd, an)
 
 
+def test_attention2_dropout_mask_statistics():
+    """The keep mask itself, read back through one-hot V rows (S <= head dim: ctx[q, k] = P[q, k] * keep[q, k] / (1 - p) with
+    uniform P): keep rate overall and per key position, independence of neighbouring keys (the two 16-bit halves of one hash
+    word and consecutive hash words), of neighbouring query rows and of neighbouring seeds (seeds of consecutive layers differ by
+    16 * 4096, of consecutive sites by 4096: stack.hip seed_of)."""
+    B, S, nh, p = 8, 56, 12, 0.1
+    H = nh * 64
+    z = torch.zeros(B, S, 3, nh, 64, device=DEV)
+    z[:, :, 2] = torch.eye(S, 64, device=DEV).view(1, S, 1, 64)  # V[key] = e_key
+    zh, zl = _split(z.view(B * S, 3 * H).contiguous())
+    addmask = torch.zeros(B * S, device=DEV)
+    ctx_hi, ctx_lo = torch.empty(B * S, H, dtype=BF16, device=DEV), torch.empty(B * S, H, dtype=BF16, device=DEV)
+    lse = torch.empty(B * nh * S, device=DEV)
+
+    def mask_of(seed):
+        ops.attn2_fwd(zh, zl, addmask, ctx_hi, ctx_lo, lse, B, S, nh, 64, p, seed)
+        c = (ctx_hi.float() + ctx_lo.float()).view(B, S, nh, 64)[..., :S] * S * (1 - p)  # [b, q, h, k] in {0, 1}
+        assert ((c - c.round()).abs().max().item() < 1e-2) and c.min().item() > -0.01 and c.max().item() < 1.01
+        return c.round().permute(0, 2, 1, 3).contiguous()  # [b, h, q, k]
+
+    seed0 = 123456789 * 4096
+    m = mask_of(seed0 + 3)
+    n = m.numel()
+    sig = (p * (1 - p) / n) ** 0.5
+    assert abs(m.mean().item() - (1 - p)) < 4 * sig, m.mean().item()
+    per_key = m.mean(dim=(0, 1, 2))
+    assert (per_key - (1 - p)).abs().max().item() < 5 * (p * (1 - p) / (n / S)) ** 0.5, per_key
+    agree = p * p + (1 - p) * (1 - p)
+    sa = (agree * (1 - agree)) ** 0.5
+
+    def check_agree(a, b, what):
+        r = (a == b).float().mean().item()
+        assert abs(r - agree) < 5 * sa / a.numel() ** 0.5, (what, r, agree)
+
+    check_agree(m[..., 0::2], m[..., 1::2], "the two halves of a hash word")
+    check_agree(m[..., 1:-1:2], m[..., 2::2], "consecutive hash words")
+    check_agree(m[:, :, :-1], m[:, :, 1:], "neighbouring query rows")
+    check_agree(m[:, :-1], m[:, 1:], "neighbouring heads")
+    for ds, what in ((1, "next seed"), (4096, "next site"), (16 * 4096, "next layer"), (4096 * 4096, "next step")):
+        check_agree(m, mask_of(seed0 + 3 + ds), what)
+
+
 def _blocked_ref(x, M, N):
     """XT[mb][n][mi] = X[64 mb + mi][n], zero rows past M."""
     mb = (M + 63) // 64
