@@ -48,6 +48,8 @@ _SIGS = {
     "vl_attn2_bwd": (c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_uint64, P]),
     "vl_ln_fwd": (c_int, [P, P, P, c_int64, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64,
                           c_int64, c_float, c_float, c_uint64, c_int64, c_int64, P]),
+    "vl_ln_fwd_rr": (c_int, [P, P, P, P, c_int64, P, P, P, P, c_float, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64,
+                             c_int64, c_float, c_float, c_uint64, c_int64, c_int64, P]),
     "vl_ln_bwd_ws_floats": (c_int64, [c_int64, c_int64]),
     "vl_ln_bwd": (c_int, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64,
                           c_float, c_float, c_uint64, c_int64, P]),

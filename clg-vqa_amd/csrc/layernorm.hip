@@ -29,6 +29,11 @@ struct LnArgs {
   // sample in the last layer): row r here is row r * orig_stride of the full problem -- the dropout counter and the
   // row masks are indexed by that ORIGINAL row (bit-identical to the dense run), resid is read at row r * resid_stride
   long orig_stride, resid_stride;
+  // residual recomputed instead of read (vl_ln_fwd_rr): the residual IS the output of an earlier LayerNorm whose saved z /
+  // mean / rstd are in memory anyway (backward needs them) -- resid[row][c] = rgamma[c] * ((rz[row][c] - rmean[row]) *
+  // rrstd[row]) + rbeta[c] (* rrow_post[row]), the very expression that LayerNorm stored; it then need not store its fp32
+  // output at all (44 MB per launch at c2)
+  const float* rz; const float* rmean; const float* rrstd; const float* rgamma; const float* rbeta; const float* rrow_post;
   // backward
   const float* dy; const float* z; float* dz; bf16_raw* dpre16; float* dpre32; float* ws; int nblk;
 };
@@ -59,6 +64,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
       if (p.resid) {
         const float4 q = *reinterpret_cast<const float4*>(p.resid + r * p.resid_stride * p.H + c);
         v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+      } else if (p.rz) {
+        const long rr = r * p.resid_stride;
+        const float4 zz = *reinterpret_cast<const float4*>(p.rz + rr * p.H + c);
+        const float4 g = *reinterpret_cast<const float4*>(p.rgamma + c);
+        const float4 bt = *reinterpret_cast<const float4*>(p.rbeta + c);
+        const float rmu = p.rmean[rr], rrs = p.rrstd[rr];
+        float4 q;
+        q.x = g.x * ((zz.x - rmu) * rrs) + bt.x;
+        q.y = g.y * ((zz.y - rmu) * rrs) + bt.y;
+        q.z = g.z * ((zz.z - rmu) * rrs) + bt.z;
+        q.w = g.w * ((zz.w - rmu) * rrs) + bt.w;
+        if (p.rrow_post) {
+          const float rq = p.rrow_post[rr];
+          q.x *= rq; q.y *= rq; q.z *= rq; q.w *= rq;
+        }
+        v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
       }
       if (p.addvec) {
         const float4 q = *reinterpret_cast<const float4*>(p.addvec + (r % p.addvec_rows) * p.H + c);
@@ -68,7 +89,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnArgs p) {
         const float rp = p.row_pre[r * p.orig_stride];
         v.x *= rp; v.y *= rp; v.z *= rp; v.w *= rp;
       }
-      if (p.p_pre > 0.f || p.resid || p.addvec || p.row_pre) *reinterpret_cast<float4*>(p.y + e) = v;  // z saved in place
+      if (p.p_pre > 0.f || p.resid || p.rz || p.addvec || p.row_pre) *reinterpret_cast<float4*>(p.y + e) = v;  // z saved in place
       z[i] = v;
       s += (v.x + v.y) + (v.z + v.w);
     }
@@ -324,12 +345,29 @@ extern "C" int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addv
                          float* rstd, int64_t M, int64_t H, int64_t group, int64_t out_stride, int64_t out_off,
                          float p_pre, float p_post, uint64_t seed, int64_t orig_row_stride, int64_t resid_row_stride,
                          void* stream) {
+  return vl_ln_fwd_rr(y32_z32, resid32, nullptr, addvec, addvec_rows, row_pre, row_post, gamma, beta, eps, out32, out_hi, out_lo, mean,
+                      rstd, M, H, group, out_stride, out_off, p_pre, p_post, seed, orig_row_stride, resid_row_stride, stream);
+}
+
+extern "C" int vl_ln_fwd_rr(float* y32_z32, const float* resid32, const int64_t* resid_ln, const float* addvec, int64_t addvec_rows,
+                            const float* row_pre, const float* row_post, const float* gamma, const float* beta, float eps,
+                            float* out32, void* out_hi, void* out_lo, float* mean, float* rstd, int64_t M, int64_t H, int64_t group,
+                            int64_t out_stride, int64_t out_off, float p_pre, float p_post, uint64_t seed,
+                            int64_t orig_row_stride, int64_t resid_row_stride, void* stream) {
   if (int rc = check_shape("vl_ln_fwd", M, H, group, p_pre, p_post)) return rc;
   VL_CHECK_ARG(y32_z32 && gamma && beta && mean && rstd && (out32 || out_hi), "vl_ln_fwd: null pointer");
   LnArgs a{};
   VL_CHECK_ARG(!addvec || addvec_rows >= 1, "vl_ln_fwd: addvec_rows must be >= 1");
   a.y = y32_z32; a.resid = resid32; a.addvec = addvec; a.addvec_rows = addvec_rows; a.row_pre = row_pre;
   a.row_post = row_post; a.gamma = gamma; a.beta = beta; a.eps = eps;
+  if (resid_ln) {  // {z32, mean, rstd, gamma, beta, row_post (may be 0)} of the LayerNorm whose output is the residual
+    VL_CHECK_ARG(!resid32, "vl_ln_fwd_rr: pass the residual OR the LayerNorm to recompute it from");
+    VL_CHECK_ARG(resid_ln[0] && resid_ln[1] && resid_ln[2] && resid_ln[3] && resid_ln[4], "vl_ln_fwd_rr: null pointer in resid_ln");
+    a.rz = reinterpret_cast<const float*>(resid_ln[0]); a.rmean = reinterpret_cast<const float*>(resid_ln[1]);
+    a.rrstd = reinterpret_cast<const float*>(resid_ln[2]); a.rgamma = reinterpret_cast<const float*>(resid_ln[3]);
+    a.rbeta = reinterpret_cast<const float*>(resid_ln[4]); a.rrow_post = reinterpret_cast<const float*>(resid_ln[5]);
+    VL_CHECK_ARG(a.rz != y32_z32, "vl_ln_fwd_rr: the residual's z buffer must not be this call's y / z buffer");
+  }
   a.out32 = out32; a.out_hi = (bf16_raw*)out_hi; a.out_lo = (bf16_raw*)out_lo; a.mean = mean; a.rstd = rstd;
   a.M = M; a.H = (int)H; a.group = group; a.out_stride = out_stride; a.out_off = out_off;
   a.p_pre = p_pre; a.inv_pre = 1.f / (1.f - p_pre); a.p_post = p_post; a.inv_post = 1.f / (1.f - p_post);

@@ -194,10 +194,23 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_CTX_HI]), ptr<void>(y[VL_LY_CTX_LO]), H, ptr<void>(y[VL_LY_WO_HI]), ptr<void>(y[VL_LY_WO_LO]), H,
                 R, H, H, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_BO]), nullptr, ptr<float>(y[VL_LY_Z1]), H, nullptr, nullptr,
                 nullptr, 0, stream));
-    VL_TRY(vl_ln_fwd(ptr<float>(y[VL_LY_Z1]), ptr<const float>(y[VL_LY_X32]), nullptr, 1, nullptr, nullptr,
-                     ptr<const float>(y[VL_LY_LN1_G]), ptr<const float>(y[VL_LY_LN1_B]), eps, ptr<float>(y[VL_LY_X1_32]),
-                     ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), ptr<float>(y[VL_LY_MEAN1]), ptr<float>(y[VL_LY_RSTD1]),
-                     R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 1), os, os, stream));
+    // The residual stream is never stored in fp32 between the LayerNorms of one call: every residual is the output of the
+    // LayerNorm before it, whose z / mean / rstd backward keeps anyway -- the consumer re-evaluates gamma * ((z - mean) * rstd) +
+    // beta (vl_ln_fwd_rr) instead of reading a copy the producer would have to write (44 MB per LayerNorm at c2).  The first
+    // layer of a call reads the caller's x32, the last one writes out32 for the caller.
+#ifdef VL_STACK_STORED_RESIDUAL  // (A/B builds: the fp32 residual stream stored by every LayerNorm and read by the next, as before)
+    constexpr bool RR = false;
+#else
+    constexpr bool RR = true;
+#endif
+    const bool rr1 = RR && l > layer_begin;  // the residual of LayerNorm 1 = output of the previous layer's LayerNorm 2
+    const int64_t* yp = y - VL_LY_FIELDS;
+    const int64_t rl1[6] = {rr1 ? yp[VL_LY_Z2] : 0, rr1 ? yp[VL_LY_MEAN2] : 0, rr1 ? yp[VL_LY_RSTD2] : 0, rr1 ? yp[VL_LY_LN2_G] : 0,
+                            rr1 ? yp[VL_LY_LN2_B] : 0, d[VL_ST_ROW_POST]};
+    VL_TRY(vl_ln_fwd_rr(ptr<float>(y[VL_LY_Z1]), rr1 ? nullptr : ptr<const float>(y[VL_LY_X32]), rr1 ? rl1 : nullptr, nullptr, 1,
+                        nullptr, nullptr, ptr<const float>(y[VL_LY_LN1_G]), ptr<const float>(y[VL_LY_LN1_B]), eps,
+                        RR ? nullptr : ptr<float>(y[VL_LY_X1_32]), ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), ptr<float>(y[VL_LY_MEAN1]), ptr<float>(y[VL_LY_RSTD1]),
+                        R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 1), os, os, stream));
     const GemmImage him{ptr<void>(y[VL_LY_T_H]), I, nullptr, nullptr};
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_X1_HI]), ptr<void>(y[VL_LY_X1_LO]), H, ptr<void>(y[VL_LY_W1_HI]), ptr<void>(y[VL_LY_W1_LO]), H,
                 R, I, H, 3, VL_EPI_GELU_SPLIT, ptr<const float>(y[VL_LY_B1]), nullptr, nullptr, 0, ptr<void>(y[VL_LY_H_HI]),
@@ -205,10 +218,12 @@ extern "C" int vl_stack_fwd(const int64_t* d, int64_t layer_begin, int64_t layer
     VL_TRY(gemm(gc, ptr<void>(y[VL_LY_H_HI]), ptr<void>(y[VL_LY_H_LO]), I, ptr<void>(y[VL_LY_W2_HI]), ptr<void>(y[VL_LY_W2_LO]), I,
                 R, H, I, 3, VL_EPI_F32, ptr<const float>(y[VL_LY_B2]), nullptr, ptr<float>(y[VL_LY_Z2]), H, nullptr, nullptr,
                 nullptr, 0, stream));
-    VL_TRY(vl_ln_fwd(ptr<float>(y[VL_LY_Z2]), ptr<const float>(y[VL_LY_X1_32]), nullptr, 1, nullptr, row_post,
-                     ptr<const float>(y[VL_LY_LN2_G]), ptr<const float>(y[VL_LY_LN2_B]), eps, ptr<float>(y[VL_LY_OUT32]),
-                     ptr<void>(y[VL_LY_OUT_HI]), ptr<void>(y[VL_LY_OUT_LO]), ptr<float>(y[VL_LY_MEAN2]), ptr<float>(y[VL_LY_RSTD2]),
-                     R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 2), os, 1, stream));
+    const int64_t rl2[6] = {y[VL_LY_Z1], y[VL_LY_MEAN1], y[VL_LY_RSTD1], y[VL_LY_LN1_G], y[VL_LY_LN1_B], 0};
+    VL_TRY(vl_ln_fwd_rr(ptr<float>(y[VL_LY_Z2]), RR ? nullptr : ptr<const float>(y[VL_LY_X1_32]), RR ? rl2 : nullptr, nullptr, 1,
+                        nullptr, row_post, ptr<const float>(y[VL_LY_LN2_G]), ptr<const float>(y[VL_LY_LN2_B]), eps,
+                        (!RR || l == layer_end - 1) ? ptr<float>(y[VL_LY_OUT32]) : nullptr,
+                        ptr<void>(y[VL_LY_OUT_HI]), ptr<void>(y[VL_LY_OUT_LO]), ptr<float>(y[VL_LY_MEAN2]), ptr<float>(y[VL_LY_RSTD2]),
+                        R, H, R, 0, 0, p_hid, 0.f, seed_of(d[VL_ST_SEED0], s3 + 2), os, 1, stream));
   }
   // training: the K-major images of the layers' X operands {layer input, attention context, LayerNorm-1 output, GELU
   // output} for the weight-gradient GEMMs of backward.  Those of the top layers (all but the bottom VL_ST_TR_BWD_LAYERS)

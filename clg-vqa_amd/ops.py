@@ -1,5 +1,6 @@
 """Thin tensor-level wrappers over the C ABI (include/vlhip.h).  Tensors are torch CUDA(=HIP) tensors used
 purely as device-memory handles; every op enqueues on torch's current stream.  CPU tensors are rejected."""
+import ctypes
 import threading
 
 import torch
@@ -254,13 +255,20 @@ def attn2_bwd(qkv_hi, addmask, dctx16, lse, dqkv16, B, S, nh, dh, p_drop, seed, 
 
 
 def ln_fwd(y, resid, addvec, gamma, beta, eps, out32, out_hi, out_lo, mean, rstd, M, H, group=None, out_stride=0,
-           out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None, orig_row_stride=1, resid_row_stride=1):
+           out_off=0, p_pre=0.0, p_post=0.0, seed=0, row_pre=None, row_post=None, orig_row_stride=1, resid_row_stride=1,
+           resid_ln=None):
+    """resid_ln = (z32, mean, rstd, gamma, beta, row_post | None) of the LayerNorm call whose output is the residual: it is
+    recomputed from those instead of read (vl_ln_fwd_rr); excludes `resid`."""
     group = M if group is None else group
     arows = 1 if addvec is None or addvec.dim() == 1 else addvec.shape[0]
-    _lib.check(_lib.lib().vl_ln_fwd(_p(y), _p(resid), _p(addvec), arows, _p(row_pre), _p(row_post), _p(gamma),
-                                    _p(beta), float(eps), _p(out32),
-                                    _p(out_hi), _p(out_lo), _p(mean), _p(rstd), M, H, group, out_stride, out_off,
-                                    float(p_pre), float(p_post), int(seed), orig_row_stride, resid_row_stride, _stream()),
+    rl = None
+    if resid_ln is not None:
+        rl = (ctypes.c_int64 * 6)(*[0 if t is None else t.data_ptr() for t in resid_ln])
+    _lib.check(_lib.lib().vl_ln_fwd_rr(_p(y), _p(resid), ctypes.cast(rl, ctypes.c_void_p) if rl is not None else None,
+                                       _p(addvec), arows, _p(row_pre), _p(row_post), _p(gamma),
+                                       _p(beta), float(eps), _p(out32),
+                                       _p(out_hi), _p(out_lo), _p(mean), _p(rstd), M, H, group, out_stride, out_off,
+                                       float(p_pre), float(p_post), int(seed), orig_row_stride, resid_row_stride, _stream()),
                "vl_ln_fwd")
 
 

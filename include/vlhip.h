@@ -199,6 +199,17 @@ int vl_ln_fwd(float* y32_z32, const float* resid32, const float* addvec, int64_t
               const float* row_post, const float* gamma, const float* beta, float eps, float* out32, void* out_hi, void* out_lo, float* mean, float* rstd, int64_t M, int64_t H,
               int64_t group, int64_t out_stride, int64_t out_off, float p_pre, float p_post, uint64_t seed,
               int64_t orig_row_stride, int64_t resid_row_stride, void* stream);
+/* The same with the residual RECOMPUTED instead of read: when the residual is the output of an earlier LayerNorm call of this
+ * library (the transformer's post-LN chain: every residual is), resid_ln = {z32, mean, rstd, gamma, beta, row_post or 0} of that
+ * call (six pointers as int64) lets this kernel re-evaluate gamma * ((z - mean) * rstd) + beta (* row_post) -- the expression that
+ * call stored -- from buffers backward keeps anyway, so that call need not store its fp32 output (out32 = NULL there: 44 MB per
+ * launch at c2).  Row r reads row r * resid_row_stride of z32 / mean / rstd / row_post.  That call must have run with
+ * p_post = 0 and the identity row map.  resid32 and resid_ln exclude each other; resid_ln = NULL is vl_ln_fwd. */
+int vl_ln_fwd_rr(float* y32_z32, const float* resid32, const int64_t* resid_ln, const float* addvec, int64_t addvec_rows,
+                 const float* row_pre, const float* row_post, const float* gamma, const float* beta, float eps, float* out32,
+                 void* out_hi, void* out_lo, float* mean, float* rstd, int64_t M, int64_t H, int64_t group, int64_t out_stride,
+                 int64_t out_off, float p_pre, float p_post, uint64_t seed, int64_t orig_row_stride, int64_t resid_row_stride,
+                 void* stream);
 /* Compact-row calls (orig_row_stride > 1): only a subset of the rows of a larger [M_full, H] problem is live -- the pooled
  * row of every sample in the last layer (encoders.py:597-608 reads hidden_states[:, 0] only).  Row r of this call is row
  * r * orig_row_stride of the full problem: the dropout counter and row_pre / row_post are indexed by that ORIGINAL row, so

@@ -304,6 +304,48 @@ def test_layernorm_forward_backward(H):
     torch.testing.assert_close(dbias.double(), zr.grad.sum(0), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("H,stride", [(768, 1), (768, 7), (128, 1)])
+def test_layernorm_recomputed_residual_is_bit_identical(H, stride):
+    """vl_ln_fwd_rr: the residual re-evaluated from the producing LayerNorm's (z, mean, rstd, gamma, beta, row_post) gives the
+    bits of the call that reads the stored fp32 output -- dense rows and the strided rows of the pooled last layer; the
+    producer then runs without an fp32 output at all."""
+    M0 = 7 * 40
+    M = M0 // stride
+    g = torch.Generator().manual_seed(5)
+    y0 = _rand(M0, H, seed=61)
+    res0 = _rand(M0, H, seed=62)
+    g0, b0 = (1.0 + 0.1 * torch.randn(H, generator=g)).to(DEV), (0.1 * torch.randn(H, generator=g)).to(DEV)
+    g1, b1 = (1.0 + 0.1 * torch.randn(H, generator=g)).to(DEV), (0.1 * torch.randn(H, generator=g)).to(DEV)
+    row_post = (torch.rand(M0, generator=g) > 0.2).float().to(DEV)
+    mean0, rstd0 = torch.empty(M0, device=DEV), torch.empty(M0, device=DEV)
+    out0 = torch.empty(M0, H, device=DEV)
+    h0, l0 = torch.empty(M0, H, dtype=BF16, device=DEV), torch.empty(M0, H, dtype=BF16, device=DEV)
+    z0 = y0.clone()
+    ops.ln_fwd(z0, res0, None, g0, b0, 1e-12, out0, h0, l0, mean0, rstd0, M0, H, p_pre=0.1, seed=9, row_post=row_post)
+    # the producer again, without its fp32 output
+    z0b, m0b, r0b = y0.clone(), torch.empty_like(mean0), torch.empty_like(rstd0)
+    h0b, l0b = torch.empty_like(h0), torch.empty_like(l0)
+    ops.ln_fwd(z0b, res0, None, g0, b0, 1e-12, None, h0b, l0b, m0b, r0b, M0, H, p_pre=0.1, seed=9, row_post=row_post)
+    assert torch.equal(z0b, z0) and torch.equal(m0b, mean0) and torch.equal(h0b, h0) and torch.equal(l0b, l0)
+    # the consumer: rows r * stride of the producer are its residual
+    y1 = _rand(M, H, seed=63)
+    outs = []
+    for mode in ("stored", "recomputed"):
+        z1, m1, r1 = y1.clone(), torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        o1 = torch.empty(M, H, device=DEV)
+        h1, l1 = torch.empty(M, H, dtype=BF16, device=DEV), torch.empty(M, H, dtype=BF16, device=DEV)
+        kw = dict(resid_row_stride=stride, orig_row_stride=stride, p_pre=0.1, seed=11)
+        if mode == "stored":
+            ops.ln_fwd(z1, out0, None, g1, b1, 1e-12, o1, h1, l1, m1, r1, M, H, **kw)
+        else:
+            ops.ln_fwd(z1, None, None, g1, b1, 1e-12, o1, h1, l1, m1, r1, M, H, resid_ln=(z0b, m0b, r0b, g0, b0, row_post), **kw)
+        outs.append((z1, m1, r1, o1, h1, l1))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        ops.ln_fwd(y1.clone(), out0, None, g1, b1, 1e-12, o1, None, None, m1, r1, M, H, resid_ln=(z0b, m0b, r0b, g0, b0, None))
+
+
 def test_layernorm_row_map_and_dropout():
     B, T, V, H = 3, 5, 7, 256
     S = T + V
