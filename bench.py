@@ -14,7 +14,7 @@ BASELINE configs through the same code (their lines are committed under profiles
 Extra objects on the line:
   roofline      the dominant kernel (the 3-pass bf16 MFMA GEMM of the forward): algorithmic FLOP (2*M*N*K per launch,
                 NOT x3 for the split passes) / duration measured live with HIP events on the launch stream inside the
-                timed region (the native stack brackets every 5th GEMM launch with caller-owned events), against the
+                timed region (the native stack brackets every 11th GEMM launch with caller-owned events), against the
                 dense bf16 MFMA peak (2.5 PFLOP/s); "mfma_issue_frac" = passes x that; "mfma_busy_pmc" and "traffic" come
                 from the newest committed rocprofv3 PMC summary of the same command (profiles/r*_summary.json).
   cpu_baseline  the oracle (CPU restatement of the reference, kind "port") timed on the box's host cores on a bounded
@@ -54,9 +54,9 @@ def executed_gflop_per_sample(workload, model, S):
 class GemmTimer(object):
     """HIP-event pairs around GEMM launches of the native stack, on the stream they run on.  Every STRIDE-th launch of
     the timed region is bracketed (an event pair is a small bubble on the stream; timing all 84 GEMMs of a step made the
-    step 4 % slower than it is).  84 launches per step and STRIDE = 5 are co-prime, so over the timed steps every GEMM
-    of the step is sampled equally often."""
-    STRIDE = 5
+    step 4 % slower than it is, every 5th 0.7 %).  The launches per step and the prime STRIDE = 11 are co-prime, so over the
+    timed steps every GEMM of the step is sampled equally often (~150 samples in the default 20 steps)."""
+    STRIDE = 11
 
     def __init__(self, stack, capacity=512):
         from clg_vqa_amd._lib import header_constants
