@@ -265,8 +265,6 @@ def main():
         model.engine.stack.tr_blocks = tuple(int(x) for x in os.environ["BENCH_TR_BLOCKS"].split(","))
     if os.environ.get("BENCH_NO_EMBED_OVERLAP", "0") == "1":  # A/B: all embedding launches on the main stream
         model.engine.embed_overlap = False
-    if os.environ.get("BENCH_NO_EMBED_BWD_OVERLAP", "0") == "1":  # A/B: the token rows' backward on the main stream
-        model.engine.embed_bwd_overlap = False
     if os.environ.get("BENCH_DW_ROWMAJOR"):  # A/B: 0 = weight gradients through the K-major re-layout pass
         model.engine.stack.dw_rowmajor = int(os.environ["BENCH_DW_ROWMAJOR"])
     if os.environ.get("BENCH_DX_TILE"):  # A/B: tile selection of the N = 768 single-pass products of backward

@@ -734,11 +734,6 @@ class UC2Engine(EngineBase):
         self.n_layers = len(model.bert.encoder.layer) // 2
         self._init_common(self.H, self.nh)
         self.embed_overlap = True  # token / box-location embeddings on the side stream beside the feature projection
-        # backward: the token rows (LayerNorm backward + the fixed-order scatter into the tables: ~190 us of latency-bound
-        # launches) on a stream of their own beside the box rows (~340 us) -- not on the weight-gradient stream, which the
-        # first layer's dW GEMM still owns at that point
-        self.embed_bwd_overlap = True
-        self._aux = None
         self.supports_update_pipeline = True
         specs = []
         for l in range(self.n_layers):
@@ -870,33 +865,6 @@ class UC2Engine(EngineBase):
         dword = None if defer else (sink if use_sink else torch.zeros_like(emb.word_embeddings.weight))
         dpos = torch.zeros_like(emb.position_embeddings.weight)
         dtype_ = torch.zeros_like(type_w)
-        # text rows (enqueued first; on their own stream they start as soon as dy and the zeroed tables are there)
-        dz_t, dg_e, db_e = f32(BT, H), f32(H), f32(H)
-        main = torch.cuda.current_stream()
-        aux = None
-        if self.embed_bwd_overlap:
-            if self._aux is None or self._aux.device != dev:
-                self._aux = torch.cuda.Stream(device=dev)
-            aux = self._aux
-            ws_t = ops.ln_bwd_ws(BT, H, dev)  # the two streams' LayerNorm reductions must not share a workspace
-            ready = torch.cuda.Event()
-            ready.record(main)  # dy (the stack's last dX product), the zero fills above, everything of earlier steps
-            aux.wait_event(ready)
-        else:
-            ws_t = ws
-        text_bwd = ops.embed_text_bwd_det if ops.DETERMINISTIC_EMBED_BWD and BT <= 16384 else ops.embed_text_bwd
-        with torch.cuda.stream(aux if aux is not None else main):  # (allocations inside belong to the stream that uses them)
-            if aux is not None:
-                ops.set_stream(aux.cuda_stream)
-            try:
-                ops.ln_bwd(dy, sv["z_t"], sv["mean_t"], sv["rstd_t"], emb.LayerNorm.weight.detach(), dz_t, None, None, dg_e,
-                           db_e, None, ws_t, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
-                # (fixed summation order: sort + run sums, csrc/scatter.hip; beyond 16384 text rows the atomic kernel)
-                text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id),
-                         row_flags=self.word_row_flags if use_sink else None)
-            finally:
-                if aux is not None:
-                    ops.set_stream(main.cuda_stream)
         # box rows
         dz_v, dg_v, db_v, dtype1 = f32(BV, H), f32(H), f32(H), f32(H)
         ops.ln_bwd(dy, sv["z_v"], sv["mean_v"], sv["rstd_v"], emb.v_LayerNorm.weight.detach(), dz_v, None, None,
@@ -911,8 +879,14 @@ class UC2Engine(EngineBase):
         dWl = torch.zeros_like(emb.image_location_embeddings.weight)
         dbl = torch.zeros_like(emb.image_location_embeddings.bias)
         ops.loc_linear_bwd(sv["locs"], dloc32, dWl, dbl, BV, L, H)
-        if aux is not None:
-            main.wait_stream(aux)  # dword / dpos / dtype_ / dz_t complete; the text rows' temporaries may be released
+        # text rows
+        dz_t, dg_e, db_e = f32(BT, H), f32(H), f32(H)
+        ops.ln_bwd(dy, sv["z_t"], sv["mean_t"], sv["rstd_t"], emb.LayerNorm.weight.detach(), dz_t, None, None, dg_e,
+                   db_e, None, ws, BT, H, group=T, out_stride=S, out_off=0, p_post=p_hid, seed=seed(1))
+        # (fixed summation order: sort + run sums, csrc/scatter.hip; beyond 16384 text rows the atomic kernel)
+        text_bwd = ops.embed_text_bwd_det if ops.DETERMINISTIC_EMBED_BWD and BT <= 16384 else ops.embed_text_bwd
+        text_bwd(sv["ids"], sv["seg"], dz_t, dword, dpos, dtype_, B, T, H, int(cfg.pad_token_id),
+                 row_flags=self.word_row_flags if use_sink else None)
         if defer:
             self._push_word_grad(sv["ids"].view(-1), dz_t, int(cfg.pad_token_id))
         dtype_[1] += dtype1  # image_token_type_embeddings is new_token_type_embeddings (embeddings.py:628)
