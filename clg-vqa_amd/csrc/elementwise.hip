@@ -364,7 +364,9 @@ __global__ __launch_bounds__(256) void loc_fwd_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void loc_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ dy,
                                                       float* dw, float* db, long R, int L, int H, float* ws) {
   __shared__ float red[4][9][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  // (the row group is the wave index: made scalar, so that the 7 box coordinates of a row -- the same for all 64 lanes -- come in
+  // through scalar loads instead of 7 vector loads per lane and row)
+  const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int cblocks = (H + 63) / 64;
   const long rb = blockIdx.x / cblocks;
   const int c = (int)(blockIdx.x - rb * cblocks) * 64 + tx;
@@ -402,22 +404,32 @@ __global__ __launch_bounds__(256) void loc_bwd_kernel(const float* __restrict__ 
       if (l < L) atomicAdd(dw + c * L + l, (red[0][l][tx] + red[1][l][tx]) + (red[2][l][tx] + red[3][l][tx]));
   }
 }
-// dw[c][l] += sum over the row blocks (fixed order, two independent chains), db likewise from slot l = 8
+// dw[c][l] += sum over the row blocks, db likewise from slot l = 8.  Fixed order: wave w adds the blocks b = w (mod 4) in
+// ascending order (two independent chains), the four partial sums are combined ((0 + 1) + (2 + 3)) through LDS -- a quarter of
+// the dependent chain of one thread per output (23 -> 8 us at c2: the launch sits on the critical path at the end of backward).
 __global__ __launch_bounds__(256) void loc_bwd_reduce_kernel(const float* __restrict__ ws, float* dw, float* db, int nrb, int L,
                                                              int H) {
-  const int c = blockIdx.x * 256 + threadIdx.x, l = blockIdx.y;  // l in [0, L] (L = the bias slot 8)
-  if (c >= H) return;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx, l = blockIdx.y;  // l in [0, L] (L = the bias slot 8)
   const int slot = l < L ? l : 8;
-  const float* src = ws + slot * (long)H + c;
   float s0 = 0.f, s1 = 0.f;
-  int b = 0;
-  for (; b + 1 < nrb; b += 2) {
-    s0 += src[(long)b * 9 * H];
-    s1 += src[(long)(b + 1) * 9 * H];
+  if (c < H) {
+    const float* src = ws + slot * (long)H + c;
+    int b = w;
+    for (; b + 4 < nrb; b += 8) {
+      s0 += src[(long)b * 9 * H];
+      s1 += src[(long)(b + 4) * 9 * H];
+    }
+    if (b < nrb) s0 += src[(long)b * 9 * H];
   }
-  if (b < nrb) s0 += src[(long)b * 9 * H];
-  if (l < L) dw[c * L + l] += s0 + s1;
-  else db[c] += s0 + s1;
+  red[w][tx] = s0 + s1;
+  __syncthreads();
+  if (w == 0 && c < H) {
+    const float t = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (l < L) dw[c * L + l] += t;
+    else db[c] += t;
+  }
 }
 
 // ---- fused AdamW over a flat arena ---------------------------------------------------------------------------
@@ -720,7 +732,7 @@ extern "C" int vl_loc_linear_bwd(const float* loc, const float* dy32, float* dw,
   hipLaunchKernelGGL(loc_bwd_kernel, dim3((unsigned)(nrb * ((H + 63) / 64))), dim3(256), 0, (hipStream_t)stream, loc, dy32, dw,
                      db, (long)R, (int)L, (int)H, ws);
   if (ws)
-    hipLaunchKernelGGL(loc_bwd_reduce_kernel, dim3((unsigned)((H + 255) / 256), (unsigned)(L + 1)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(loc_bwd_reduce_kernel, dim3((unsigned)((H + 63) / 64), (unsigned)(L + 1)), dim3(256), 0, (hipStream_t)stream,
                        ws, dw, db, (int)nrb, (int)L, (int)H);
   VL_CHECK_LAUNCH("vl_loc_linear_bwd");
   return 0;
