@@ -31,14 +31,17 @@ struct ScArgs {
 // (key, source index) pairs of table tb -> s[0, R): the table row in the high word (SC_NONE: receives nothing)
 __device__ __forceinline__ void sc_stage_keys(const ScTable& tb, unsigned long long* s, int R, int tid) {
   if (tb.kind == 1) {
-    // RoBERTa position ids: (number of non-pad ids in [0, t] of the sample, 0 for a pad) + pad id -- one thread walks one
-    // sample (a running count instead of a re-count per token)
+    // RoBERTa position ids: (number of non-pad ids in [0, t] of the sample, 0 for a pad) + pad id.  The ids go to LDS with
+    // coalesced loads first; then one thread walks one sample there (a running count instead of a re-count per token, LDS
+    // reads instead of T global loads one after the other)
     const int T = tb.T;
+    for (int i = tid; i < R; i += 256) s[i] = (unsigned long long)tb.ids[i];
+    __syncthreads();
     for (int b = tid; b < R / T; b += 256) {
       int cnt = 0;
       for (int t = 0; t < T; ++t) {
         const int i = b * T + t;
-        const bool nz = tb.ids[i] != tb.skip;
+        const bool nz = (int64_t)s[i] != tb.skip;
         cnt += nz;
         s[i] = ((unsigned long long)(unsigned)((nz ? cnt : 0) + (int)tb.skip) << 32) | (unsigned)i;
       }
@@ -51,9 +54,11 @@ __device__ __forceinline__ void sc_stage_keys(const ScTable& tb, unsigned long l
   }
 }
 
-// Rank sort: every workgroup stages all R keys of its table in LDS; thread i counts the keys below its own (all lanes read
-// the same LDS word: a broadcast) and writes its pair to sorted[rank].  O(R^2) compares, but spread over R / 256 workgroups
-// (R = 5120: 20 workgroups x 5120 compares per thread) -- a one-workgroup bitonic sort of the same keys took ~250 us.
+// Rank sort: every workgroup stages all R keys of its table in LDS and ranks 64 of them: four threads per key, thread p counting
+// the keys j = p (mod 4) below its own (the four lanes of a key read 32 contiguous bytes, the 16 keys of a wave the same ones: a
+// broadcast), the four counts added across the lanes; the pair goes to sorted[rank].  O(R^2) compares spread over R / 64
+// workgroups (R = 5120: 80 workgroups per table x 1280 compares per thread; 20 workgroups x 5120 took 70 us, a one-workgroup
+// bitonic sort of the same keys ~250 us).
 __global__ __launch_bounds__(256) void sc_sort_kernel(ScArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* s = reinterpret_cast<unsigned long long*>(smem_raw);
@@ -61,18 +66,23 @@ __global__ __launch_bounds__(256) void sc_sort_kernel(ScArgs a) {
   const int tid = threadIdx.x;
   sc_stage_keys(tb, s, a.R, tid);
   __syncthreads();
-  const int i = blockIdx.x * 256 + tid;
-  if (i >= a.Rp) return;
+  const int i = blockIdx.x * 64 + (tid >> 2), part = tid & 3;
   unsigned long long* out = a.sorted + (long)blockIdx.y * a.Rp;
-  if (i >= a.R) { out[i] = ~0ull; return; }  // the real pairs take ranks [0, R): the tail is padding
-  const unsigned long long mine = s[i];
+  const bool real = i < a.R;
+  const unsigned long long mine = real ? s[i] : ~0ull;
+  int rank = 0;
+  if (real) {
+    int j = part;
+    for (; j + 12 < a.R; j += 16)
+      rank += (int)(s[j] < mine) + (int)(s[j + 4] < mine) + (int)(s[j + 8] < mine) + (int)(s[j + 12] < mine);
+    for (; j < a.R; j += 4) rank += (int)(s[j] < mine);
+  }
+  rank += __shfl_xor(rank, 1, 64);
+  rank += __shfl_xor(rank, 2, 64);
+  if (part != 0 || i >= a.Rp) return;
+  if (!real) { out[i] = ~0ull; return; }  // the real pairs take ranks [0, R): the tail is padding
   const unsigned row = (unsigned)(mine >> 32);
   if (row != SC_NONE && tb.flags) tb.flags[row] = 1;  // this table row now carries optimizer state
-  int rank = 0;
-  int j = 0;
-  for (; j + 4 <= a.R; j += 4)
-    rank += (int)(s[j] < mine) + (int)(s[j + 1] < mine) + (int)(s[j + 2] < mine) + (int)(s[j + 3] < mine);
-  for (; j < a.R; ++j) rank += (int)(s[j] < mine);
   out[rank] = mine;
 }
 
@@ -264,7 +274,7 @@ extern "C" int vl_scatter_add_det(const int64_t* tab, int64_t n, const float* dz
     attr_set = true;
   }
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(sc_sort_kernel, dim3((unsigned)((a.Rp + 255) / 256), (unsigned)n), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(sc_sort_kernel, dim3((unsigned)((a.Rp + 63) / 64), (unsigned)n), dim3(256), lds, s, a);
   const dim3 grid((unsigned)((a.nblocks + 3) / 4), (unsigned)n);
   const int nv = (int)(H / 64);
 #define SC_LAUNCH(NVT)                                                          \
